@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RealNVP log_prob evals/sec at batch 2^20 per GPU.
+
+A "step" is one pass of the hot path over one resident batch: the fused
+coupling-chain kernel writes log_prob for every row and the per-block float64
+partial sums, a second tiny kernel adds them in a fixed order, (N > 1: one RCCL
+all-reduce of that one float64), and the scalar lands in pinned host memory.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by `python -m torch.distributed.run`; torch.distributed (gloo,
+CPU) is used only for the rendezvous, the barrier and the max-over-ranks of the
+timing.  All GPU work goes through libnf_hip.so (own stream, own RCCL
+communicator); torch never touches the device.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# measured/spec constants: /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, spec (155 measured)
+FLOP_PER_EVAL_L8 = 69632       # L * 2 * (2*64 + 64*64 + 64*2), L = 8
+BYTES_PER_EVAL = 12            # 8 B in (x[2] f32) + 4 B out (log_prob f32)
+
+
+def cpu_baseline(spec, density):
+    """The NumPy float32 restatement (oracle) timed on this host: a reported
+    baseline ("port"), not the target.  Bounded sample of the same workload."""
+    from oracle import flows_np as O
+    rows = 1 << 18
+    x = O.make_inputs(density, rows)
+    O.log_prob(spec, x[:4096], np.float32)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.log_prob(spec, x, np.float32)
+        reps += 1
+        if time.perf_counter() - t0 > 8.0:
+            break
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": rows * reps / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"NumPy float32 restatement (oracle/flows_np.py), {reps} x 2^18 rows of the same "
+                      f"8-layer flow on {density}; host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU (weak scaling)")
+    ap.add_argument("--density", default="banana")
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
+                     "--nproc-per-node N (one rank per GPU)")
+        args.gpus = world
+
+    from normalizing_flows_amd import _lib, flow
+    from oracle import flows_np as O   # synthetic weights/inputs + the cpu_baseline leg only
+
+    lib = _lib.load()
+    _lib.require_device()
+    _lib.check(lib.nf_set_device(local_rank))
+
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist  # gloo: CPU-side rendezvous only
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from normalizing_flows_amd import sharding
+        comm = sharding.RcclComm.from_torch_distributed(dist)
+
+    spec = O.make_affine_spec(args.layers, final_std=0.02)
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=args.layers, hidden=(64, 64))
+    f = flow.CouplingFlow(cfg, spec.layers)
+    if comm is not None:
+        f.attach_comm(comm)
+
+    rows = args.rows
+    rows_global = rows * world
+    # every rank owns its own rows of the global batch (different seed per rank)
+    x = O.make_inputs(args.density, rows, seed=2123 + rank)
+    xd = flow.DeviceArray.from_numpy(x)
+    lpd = flow.DeviceArray((rows,))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        f.nll_enqueue(xd, rows_global, i % _lib.NF_NLL_SLOTS, lpd)
+    f.synchronize()
+    _lib.check(lib.nf_device_synchronize())
+    barrier()
+
+    t0 = time.perf_counter()
+    f.timer_start()
+    for i in range(args.steps):
+        f.nll_enqueue(xd, rows_global, i % _lib.NF_NLL_SLOTS, lpd)
+    ev_ms = f.timer_stop()          # HIP events on the stream the kernels ran on
+    _lib.check(lib.nf_device_synchronize())
+    barrier()
+    wall = time.perf_counter() - t0
+
+    nll = f.nll_result((args.steps - 1) % _lib.NF_NLL_SLOTS)
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = rows_global * args.steps / wall
+        # dominant kernel: the fused chain; its launch duration ~ event time per step
+        # (the 1-block sum kernel and the 8-byte copy are < 1 % of it)
+        kern_s = ev_ms * 1e-3 / args.steps
+        flop_per_eval = FLOP_PER_EVAL_L8 * args.layers / 8
+        achieved_tflops = rows * flop_per_eval / kern_s / 1e12
+        out = {
+            "metric": "log_prob evals/sec (batch=2^20 per GPU)", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"RealNVP {args.layers} affine coupling layers (MLP 2-64-64-2), 2-D "
+                                   f"{args.density}, batch=2^{int(np.log2(rows))} per GPU, log_prob + NLL",
+                       "rows_per_gpu": rows, "rows_global": rows_global, "kernel": f.kernel_name,
+                       "parallelism": f"dp{world} (batch rows sharded, one RCCL all-reduce of one f64)"},
+            "nll": nll,
+            "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None,
+                         "hbm_algorithmic_GBps": rows * BYTES_PER_EVAL / kern_s / 1e9,
+                         "kernel_ms": kern_s * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(spec, args.density)
+        print(json.dumps(out))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+/*
+ * nf_hip.h -- C ABI of libnf_hip.so: coupling-flow log_prob hot path on MI355X (gfx950).
+ *
+ * The reference (kaijennissen/Normalizing_Flows) is pure Python and has no FFI
+ * for this path; the seam it does have is the Python-level distrax protocol
+ * (SURVEY.md section 8b).  Every entry point below names the reference
+ * function(s) it replaces as file:line relative to the reference root.  The
+ * Python side that binds these with ctypes is normalizing_flows_amd/_lib.py;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (NF_OK) or a negative nf_status; nothing throws
+ *     across the ABI; nf_last_error() returns a thread-local message.
+ *   - the caller owns all host buffers; the library owns device buffers behind
+ *     opaque handles.  A handle has one HIP stream; a handle is not thread-safe,
+ *     distinct handles may be used from distinct threads.
+ *   - sample matrices are row-major float32 [rows, event_dim]; per-sample
+ *     vectors are float32 [rows].
+ *   - `mem` says where x / y / out pointers live: NF_MEM_HOST (the library
+ *     stages through its own device buffers) or NF_MEM_DEVICE (device pointers,
+ *     e.g. from nf_malloc; no copies, work is only enqueued on the handle's
+ *     stream and the caller synchronises with nf_flow_synchronize).
+ */
+#ifndef NF_HIP_H
+#define NF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_ABI_VERSION 1
+#define NF_MAX_HIDDEN 8
+
+typedef enum nf_status {
+  NF_OK = 0,
+  NF_ERR_INVALID = -1,     /* bad argument / shape (the reference raises ValueError) */
+  NF_ERR_HIP = -2,         /* a HIP runtime call failed */
+  NF_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for */
+  NF_ERR_NO_DEVICE = -4,   /* no gfx950 device visible */
+  NF_ERR_COMM = -5,        /* RCCL missing or a collective failed */
+  NF_ERR_STATE = -6        /* call order (e.g. log_prob before set_weights) */
+} nf_status;
+
+typedef enum nf_kind {
+  /* src/real_nvp.py:71-171  split halves + flip, MLP conditioner with leaky_relu,
+     (shift, log_scale) = split(out, 2) of width event_dim/2 each */
+  NF_KIND_AFFINE_SPLIT = 0,
+  /* src/real_nvp_toy_densities.py:74-110  distrax.MaskedCoupling(ScalarAffine):
+     conditioner emits 2 numbers per sample, broadcast over every event dim */
+  NF_KIND_AFFINE_MASKED = 1,
+  /* src/maf_toy_densities.py:74-111, src/maf_mnist.py:52-89
+     distrax.MaskedCoupling(RationalQuadraticSpline): conditioner emits
+     event_dim * (3*bins+1) numbers */
+  NF_KIND_RQS_MASKED = 2
+} nf_kind;
+
+typedef enum nf_activation { NF_ACT_RELU = 0, NF_ACT_LEAKY_RELU = 1 /* slope 0.01 */ } nf_activation;
+typedef enum nf_base {
+  NF_BASE_STD_NORMAL = 0, /* Independent(Normal(0,1)) / MultivariateNormalDiag(0,I) */
+  NF_BASE_UNIFORM01 = 1   /* Independent(Uniform(0,1)): 0 inside [0,1]^D, -inf outside */
+} nf_base;
+typedef enum nf_mem { NF_MEM_HOST = 0, NF_MEM_DEVICE = 1 } nf_mem;
+
+/* Which way a chain is walked and which per-layer map is applied. */
+typedef enum nf_direction {
+  /* distrax.Chain.forward_and_log_det: LAST layer first, each layer's forward map
+     y_t = x_t*exp(ls)+shift (affine) or spline forward.  This is what
+     Transformed(base, Inverse(Chain)).log_prob runs
+     (src/real_nvp_toy_densities.py:104,123). */
+  NF_DIR_CHAIN_FORWARD = 0,
+  /* distrax.Chain.inverse_and_log_det: layer 0 first, each layer's inverse map.
+     This is what Transformed.sample runs (src/real_nvp_toy_densities.py:136). */
+  NF_DIR_CHAIN_INVERSE = 1,
+  /* src/real_nvp.py:228-248 sample_nvp_chain: layer 0 first, forward_nvp. */
+  NF_DIR_FIRST_TO_LAST_FORWARD = 2,
+  /* src/real_nvp.py:251-283 log_prob_nvp_chains: last layer first, inverse_nvp. */
+  NF_DIR_LAST_TO_FIRST_INVERSE = 3
+} nf_direction;
+
+typedef struct nf_flow_desc {
+  int32_t abi_version;             /* NF_ABI_VERSION */
+  int32_t kind;                    /* nf_kind */
+  int32_t event_dim;               /* D: flattened event size (2 toy, 784 MNIST) */
+  int32_t num_layers;              /* L coupling layers */
+  int32_t num_hidden;              /* hidden Linear layers of the conditioner MLP */
+  int32_t hidden[NF_MAX_HIDDEN];   /* their widths */
+  int32_t activation;              /* nf_activation */
+  /* masked kinds: layer l passes through (and shows the conditioner) the dims d
+     with (d % 2 == first_mask_parity) XOR (l odd); reference value 1
+     (src/real_nvp_toy_densities.py:80-82,102).
+     split kind: layer l flips iff (l odd) XOR first_mask_parity; reference value 0
+     (src/real_nvp.py:209-218). */
+  int32_t first_mask_parity;
+  int32_t base;                    /* nf_base */
+  int32_t rqs_bins;                /* K (RQS kind only) */
+  float rqs_range_min, rqs_range_max;
+  float rqs_min_bin_size, rqs_min_knot_slope; /* distrax defaults 1e-4, 1e-4 */
+} nf_flow_desc;
+
+typedef struct nf_flow nf_flow;
+typedef struct nf_comm nf_comm;
+
+/* ---- library / device ------------------------------------------------- */
+int nf_abi_version(void);
+const char* nf_last_error(void);
+int nf_device_count(int* out_count);
+int nf_set_device(int device);
+int nf_device_name(int device, char* buf, size_t buf_len);
+int nf_device_synchronize(void);
+
+/* plain device memory for callers that keep batches resident in HBM */
+int nf_malloc(void** out_ptr, size_t bytes);
+int nf_free(void* ptr);
+int nf_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int nf_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- flow handle ------------------------------------------------------- */
+/* Number of float32 values nf_flow_set_weights expects for `desc`
+   (sum over layers and Linear modules of in*out + out). */
+int nf_flow_weight_count(const nf_flow_desc* desc, size_t* out_count);
+
+/* Replaces make_flow_model (src/real_nvp_toy_densities.py:74-110,
+   src/maf_toy_densities.py:74-111, src/maf_mnist.py:52-89) and init_nvp_chain's
+   structure (src/real_nvp.py:198-220): builds the chain on the current device. */
+int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow);
+void nf_flow_destroy(nf_flow* flow);
+
+/* Host->device upload of all conditioner parameters.  `packed` is layer-major;
+   inside a layer the Linear modules in creation order, each as W [in,out]
+   row-major (y = x @ W + b, the haiku / src/real_nvp.py:190-194 orientation)
+   followed by b [out].  For masked kinds the first Linear has in = event_dim and
+   the last has out = 2 (affine) or event_dim*(3K+1) (RQS); for the split kind
+   in = event_dim/2, out = event_dim. */
+int nf_flow_set_weights(nf_flow* flow, const float* packed, size_t count);
+
+/* Name of the kernel family the handle dispatches to ("affine2d_h64_mfma",
+   "split2d_small", "generic_gemm"); for diagnostics and tests. */
+int nf_flow_kernel_name(const nf_flow* flow, char* buf, size_t buf_len);
+int nf_flow_synchronize(nf_flow* flow);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Replaces log_prob.apply -> distrax.Transformed.log_prob
+   (src/real_nvp_toy_densities.py:113-123, src/maf_toy_densities.py:112-125,
+   src/maf_mnist.py:109-118) and log_prob_nvp_chains with log_prob_N01
+   (src/real_nvp.py:57-68,268-283).  out_log_prob[rows]. */
+int nf_log_prob(nf_flow* flow, const float* x, int64_t rows, float* out_log_prob, int mem);
+
+/* Replaces Chain / MaskedCoupling forward_and_log_det, inverse_and_log_det and
+   forward_nvp / inverse_nvp chains (see nf_direction).  Walks layers
+   [layer_begin, layer_end) of the chain; pass 0, num_layers for the whole chain,
+   l, l+1 for the single MaskedCoupling l.  y[rows, D], logdet[rows]; either
+   output may be NULL. */
+int nf_chain_apply(nf_flow* flow, int direction, int layer_begin, int layer_end,
+                   const float* x, int64_t rows, float* y, float* logdet, int mem);
+
+/* Replaces loss_fn / eval_fn: -mean(log_prob) (src/real_nvp_toy_densities.py:139-151,
+   src/real_nvp.py:292-293).  Sums log_prob over the local rows in float64 in a
+   fixed order; when a communicator is attached the local sum is all-reduced
+   (RCCL, one float64) before dividing by rows_global.  out_log_prob may be NULL
+   or receive the per-sample values as nf_log_prob does.  Blocking: *out_nll is
+   valid on return. */
+int nf_nll(nf_flow* flow, const float* x, int64_t rows_local, int64_t rows_global,
+           float* out_log_prob, double* out_nll, int mem);
+
+/* Same work, enqueue only (device pointers only): the scalar is written to
+   slot `slot` (0..NF_NLL_SLOTS-1) of a pinned host ring the handle owns; read it
+   with nf_nll_result after nf_flow_synchronize. */
+#define NF_NLL_SLOTS 64
+int nf_nll_enqueue(nf_flow* flow, const float* x_dev, int64_t rows_local, int64_t rows_global,
+                   float* out_log_prob_dev, int slot);
+int nf_nll_result(nf_flow* flow, int slot, double* out_nll);
+
+/* ---- stream timing (bench.py: HIP events on the stream the kernels run on) */
+int nf_timer_start(nf_flow* flow);
+int nf_timer_stop(nf_flow* flow, float* out_ms); /* synchronises on the stop event */
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
+/* librccl.so.1 is dlopen'ed on first use; a build box without it still loads
+   libnf_hip.so.  id is an ncclUniqueId (128 bytes) made on rank 0 and handed to
+   the other ranks by the host (bench.py uses torch.distributed's store). */
+#define NF_COMM_ID_BYTES 128
+int nf_comm_unique_id(unsigned char id[NF_COMM_ID_BYTES]);
+int nf_comm_init_rank(nf_comm** out_comm, int world_size, int rank,
+                      const unsigned char id[NF_COMM_ID_BYTES]);
+int nf_comm_destroy(nf_comm* comm);
+int nf_flow_attach_comm(nf_flow* flow, nf_comm* comm); /* NULL detaches */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NF_HIP_H */

@@ -1,0 +1,282 @@
+// Fused chain of masked affine coupling layers, event_dim = 2, conditioner
+// 2 -> 64 -> 64 -> 2 with relu (variant B of the reference:
+// src/real_nvp_toy_densities.py:56-123 + distrax MaskedCoupling / ScalarAffine /
+// Chain / Transformed semantics).
+//
+// One launch walks every layer for every sample and writes log_prob (and/or the
+// transformed sample and the log-det-Jacobian).  gfx950 only.
+//
+// Mapping onto CDNA4
+//   * The 64x64 hidden Linear is 94 % of the FLOPs.  It runs on the exact-f32
+//     matrix instruction v_mfma_f32_32x32x2_f32 with the OUTPUT UNITS on the
+//     rows and 32 SAMPLES on the columns:  D[u][i] += W2[k][u] * h1[k][i].
+//     A (weights) lane (u,h) holds W2[2s+h][32m+u]; B (activations) lane (i,h)
+//     holds h1[2s+h] of sample i; D lane (i,h) holds, for its sample i, the 16
+//     units 8(r>>2)+4h+(r&3) of M-tile m in registers r.
+//   * The first Linear has ONE live input (the masked event dim is zero), so
+//     its output h1[k] = relu(x_c*w1[k]+b1[k]) is produced directly in the B
+//     operand's register layout: one v_fma + one v_max per k-step, no LDS
+//     round trip for activations.
+//   * b2 enters as the C operand of the first k-step.  The last Linear (64->2)
+//     is lane-local: each lane reduces its 32 units against W3 rows held in the
+//     accumulator's order, and one v_permlane32_swap adds the two half-waves.
+//   * All layers' weights sit in LDS (17,680 B per layer, pre-arranged on the
+//     host in operand order, so every LDS read is a contiguous ds_read_b64 /
+//     b128 or a broadcast); one 512-thread workgroup per CU, two waves per
+//     SIMD so one wave's epilogue overlaps the other's MFMA stream.
+//   * HBM traffic is 8 B in + 4..12 B out per sample: the kernel is bound by
+//     the f32 MFMA rate, not by HBM.
+#include "nf_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace nf {
+namespace affine2d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ host pack
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2,
+                const float* W3, const float* b3, int cond_dim, float* img) {
+  memset(img, 0, sizeof(float) * kLayerFloats);
+  for (int s = 0; s < 32; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int m = 0; m < 2; ++m) {
+        const int k = 2 * s + (lane >> 5);
+        const int u = 32 * m + (lane & 31);
+        img[kA2 + (s * 64 + lane) * 2 + m] = W2[k * kHidden + u];
+      }
+  for (int k = 0; k < 64; ++k) {
+    img[kW1B1 + 2 * k + 0] = W1[cond_dim * kHidden + k];
+    img[kW1B1 + 2 * k + 1] = b1[k];
+  }
+  for (int h = 0; h < 2; ++h)
+    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) {
+        const int u = 32 * m + 8 * (r >> 2) + 4 * h + (r & 3);
+        img[kB2 + (h * 2 + m) * 16 + r] = b2[u];
+        img[kW3 + ((h * 2 + m) * 16 + r) * 2 + 0] = W3[u * 2 + 0];
+        img[kW3 + ((h * 2 + m) * 16 + r) * 2 + 1] = W3[u * 2 + 1];
+      }
+  img[kB3 + 0] = b3[0];
+  img[kB3 + 1] = b3[1];
+}
+
+// ------------------------------------------------------------------ device
+struct Params {
+  const float* wimg;
+  ChainIO io;
+  int first_mask_parity;
+};
+
+__device__ __forceinline__ float add_halves(float v) {
+  // sum of lane l and lane l^32, bit-identical in both lanes
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ f32x16 lds_f32x16(const float* p) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 v;
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+  v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+  return v;
+}
+
+// T = 32-sample column tiles a wave carries through the chain at once.
+template <int T>
+__global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ChainIO& io = p.io;
+  const int tid = threadIdx.x;
+  const int nlay = io.layer_end - io.layer_begin;
+
+  // stage the images of the layers this launch walks (contiguous in wimg)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wimg + (size_t)io.layer_begin * kLayerFloats);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = nlay * (kLayerFloats / 4);
+    for (int q = tid; q < n4; q += kThreads) dst[q] = src[q];
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i = lane & 31;  // sample column inside a tile
+  const int h = lane >> 5;  // half-wave: k parity (operands), unit group (accumulator)
+  const long long rows = io.rows;
+  const long long groups = (rows + (T * 32 - 1)) / (T * 32);
+  const float2* __restrict__ xin = reinterpret_cast<const float2*>(io.x);
+
+  double wave_sum = 0.0;
+
+  for (long long g = (long long)blockIdx.x * 8 + wave; g < groups; g += (long long)gridDim.x * 8) {
+    const int l_first = io.descending ? io.layer_end - 1 : io.layer_begin;
+    const int c_first = (p.first_mask_parity + l_first) & 1;  // dim the first walked layer conditions on
+
+    float xc[T], xt[T], ld[T];
+    long long idx[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      idx[t] = g * (T * 32) + t * 32 + i;
+      float2 v = make_float2(0.f, 0.f);
+      if (idx[t] < rows) v = xin[idx[t]];
+      xc[t] = c_first ? v.y : v.x;
+      xt[t] = c_first ? v.x : v.y;
+      ld[t] = (io.logdet_in != nullptr && idx[t] < rows) ? io.logdet_in[idx[t]] : 0.f;
+    }
+
+    for (int li = 0; li < nlay; ++li) {
+      const int lrel = io.descending ? nlay - 1 - li : li;
+      const float* L = lds + lrel * kLayerFloats;
+      const float2* a2 = reinterpret_cast<const float2*>(L + kA2) + lane;   // + s*64
+      const float2* w1b1 = reinterpret_cast<const float2*>(L + kW1B1) + h;  // + 2*s
+
+      f32x16 acc[T][2];
+      {
+        const f32x16 bias0 = lds_f32x16(L + kB2 + (h * 2 + 0) * 16);
+        const f32x16 bias1 = lds_f32x16(L + kB2 + (h * 2 + 1) * 16);
+        const float2 a = a2[0];
+        const float2 wb = w1b1[0];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float b = fmaxf(fmaf(xc[t], wb.x, wb.y), 0.f);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
+        }
+      }
+#pragma unroll 8
+      for (int s = 1; s < 32; ++s) {
+        const float2 a = a2[s * 64];
+        const float2 wb = w1b1[2 * s];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float b = fmaxf(fmaf(xc[t], wb.x, wb.y), 0.f);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[t][1], 0, 0, 0);
+        }
+      }
+
+      // last Linear (64 -> 2) on the accumulator, then the affine map
+      const float4* w3 = reinterpret_cast<const float4*>(L + kW3 + h * 64);
+      const float b3s = L[kB3 + 0], b3l = L[kB3 + 1];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float ps = 0.f, pl = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float4 w = w3[(m * 16 + r) / 2];
+            const float v0 = fmaxf(acc[t][m][r], 0.f);
+            const float v1 = fmaxf(acc[t][m][r + 1], 0.f);
+            ps = fmaf(v0, w.x, ps);
+            pl = fmaf(v0, w.y, pl);
+            ps = fmaf(v1, w.z, ps);
+            pl = fmaf(v1, w.w, pl);
+          }
+        const float shift = add_halves(ps) + b3s;
+        const float ls = add_halves(pl) + b3l;
+        float nt;
+        if (io.inverse_op) {
+          nt = (xt[t] - shift) * expf(-ls);
+          ld[t] -= ls;
+        } else {
+          nt = fmaf(xt[t], expf(ls), shift);
+          ld[t] += ls;
+        }
+        // masks alternate: the dim just transformed conditions the next layer
+        xt[t] = xc[t];
+        xc[t] = nt;
+      }
+    }
+
+    // after nlay swaps xc holds dim c_first when nlay is even, the other dim when odd
+    const int c_last = (c_first + nlay) & 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float v0 = c_last ? xt[t] : xc[t];
+      const float v1 = c_last ? xc[t] : xt[t];
+      float lp = ld[t];
+      if (io.add_base) {
+        if (io.base == NF_BASE_STD_NORMAL) {
+          lp += -0.5f * (v0 * v0 + v1 * v1) - 1.8378770664093453f;  // D/2 * log(2 pi), D = 2
+        } else {
+          const bool inside = v0 >= 0.f && v0 <= 1.f && v1 >= 0.f && v1 <= 1.f;
+          if (!inside) lp = -INFINITY;
+        }
+      }
+      if (h == 0 && idx[t] < rows) {
+        if (io.y) reinterpret_cast<float2*>(io.y)[idx[t]] = make_float2(v0, v1);
+        if (io.logdet_out) io.logdet_out[idx[t]] = ld[t];
+        if (io.logprob_out) io.logprob_out[idx[t]] = lp;
+        wave_sum += (double)lp;
+      }
+    }
+  }
+
+  if (io.block_sums) {
+    // every wave reaches this point: reduce lanes, then the 8 waves, in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_down(wave_sum, off);
+    __syncthreads();  // all waves are done with the weight images
+    double* red = reinterpret_cast<double*>(lds);
+    if (lane == 0) red[wave] = wave_sum;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < 8; ++w) s += red[w];
+      io.block_sums[blockIdx.x] = s;
+    }
+  }
+}
+
+int max_grid() { return 256; }
+
+template <int T>
+static int launch_t(const Params& p, int grid, size_t lds_bytes, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chain_kernel<T>, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid_cap,
+           hipStream_t stream, int* out_grid) {
+  const int nlay = io.layer_end - io.layer_begin;
+  if (nlay < 1 || nlay > kMaxResidentLayers) {
+    set_error("affine2d launch walks %d layers, at most %d fit in LDS", nlay, kMaxResidentLayers);
+    return NF_ERR_INVALID;
+  }
+  Params p;
+  p.wimg = wimg;
+  p.io = io;
+  p.first_mask_parity = first_mask_parity;
+  const size_t lds_bytes = (size_t)nlay * kLayerFloats * sizeof(float) + 64;
+  const int cap = grid_cap > 0 && grid_cap < max_grid() ? grid_cap : max_grid();
+  // pick the tile count so that small batches still spread over the chip
+  int T = 4;
+  if (io.rows < (long long)cap * 8 * 128) T = 2;
+  if (io.rows < (long long)cap * 8 * 64) T = 1;
+  const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
+  long long want = (groups + 7) / 8;
+  int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+  if (out_grid) *out_grid = grid;
+  switch (T) {
+    case 4: return launch_t<4>(p, grid, lds_bytes, stream);
+    case 2: return launch_t<2>(p, grid, lds_bytes, stream);
+    default: return launch_t<1>(p, grid, lds_bytes, stream);
+  }
+}
+
+}  // namespace affine2d
+}  // namespace nf

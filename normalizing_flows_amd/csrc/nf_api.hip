@@ -1,0 +1,506 @@
+// C ABI of libnf_hip.so (include/nf_hip.h): handles, weight packing, dispatch.
+#include "nf_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+namespace nf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return e == hipErrorNoDevice ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
+}
+
+enum Path { PATH_AFFINE2D_H64 = 0, PATH_SPLIT2D_SMALL = 1, PATH_GENERIC = 2 };
+
+static const char* path_name(int p) {
+  switch (p) {
+    case PATH_AFFINE2D_H64: return "affine2d_h64_mfma";
+    case PATH_SPLIT2D_SMALL: return "split2d_small";
+    default: return "generic_gemm";
+  }
+}
+
+// sizes of the Linear modules of one coupling layer's conditioner: in[j], out[j]
+static void linear_shapes(const nf_flow_desc& d, std::vector<int>& in, std::vector<int>& out) {
+  in.clear();
+  out.clear();
+  int first_in, last_out;
+  if (d.kind == NF_KIND_AFFINE_SPLIT) {
+    first_in = d.event_dim / 2;
+    last_out = d.event_dim;
+  } else if (d.kind == NF_KIND_AFFINE_MASKED) {
+    first_in = d.event_dim;
+    last_out = 2;
+  } else {
+    first_in = d.event_dim;
+    last_out = d.event_dim * (3 * d.rqs_bins + 1);
+  }
+  int cur = first_in;
+  for (int j = 0; j < d.num_hidden; ++j) {
+    in.push_back(cur);
+    out.push_back(d.hidden[j]);
+    cur = d.hidden[j];
+  }
+  in.push_back(cur);
+  out.push_back(last_out);
+}
+
+static int validate_desc(const nf_flow_desc* d) {
+  if (!d) { set_error("desc is NULL"); return NF_ERR_INVALID; }
+  if (d->abi_version != NF_ABI_VERSION) {
+    set_error("desc.abi_version %d, library speaks %d", d->abi_version, NF_ABI_VERSION);
+    return NF_ERR_INVALID;
+  }
+  if (d->kind < NF_KIND_AFFINE_SPLIT || d->kind > NF_KIND_RQS_MASKED) {
+    set_error("unknown flow kind %d", d->kind); return NF_ERR_INVALID;
+  }
+  if (d->event_dim < 2) { set_error("event_dim must be >= 2, got %d", d->event_dim); return NF_ERR_INVALID; }
+  if (d->kind == NF_KIND_AFFINE_SPLIT && (d->event_dim & 1)) {
+    set_error("split coupling needs an even event_dim, got %d", d->event_dim); return NF_ERR_INVALID;
+  }
+  if (d->num_layers < 1) { set_error("num_layers must be >= 1"); return NF_ERR_INVALID; }
+  if (d->num_hidden < 1 || d->num_hidden > NF_MAX_HIDDEN) {
+    set_error("num_hidden must be 1..%d, got %d", NF_MAX_HIDDEN, d->num_hidden); return NF_ERR_INVALID;
+  }
+  for (int j = 0; j < d->num_hidden; ++j)
+    if (d->hidden[j] < 1) { set_error("hidden[%d] must be positive", j); return NF_ERR_INVALID; }
+  if (d->activation != NF_ACT_RELU && d->activation != NF_ACT_LEAKY_RELU) {
+    set_error("unknown activation %d", d->activation); return NF_ERR_INVALID;
+  }
+  if (d->base != NF_BASE_STD_NORMAL && d->base != NF_BASE_UNIFORM01) {
+    set_error("unknown base distribution %d", d->base); return NF_ERR_INVALID;
+  }
+  if (d->first_mask_parity != 0 && d->first_mask_parity != 1) {
+    set_error("first_mask_parity must be 0 or 1"); return NF_ERR_INVALID;
+  }
+  if (d->kind == NF_KIND_RQS_MASKED) {
+    // the checks distrax.RationalQuadraticSpline makes in its constructor
+    if (d->rqs_bins < 1) { set_error("rqs_bins must be >= 1"); return NF_ERR_INVALID; }
+    if (!(d->rqs_range_min < d->rqs_range_max)) { set_error("rqs range_min must be below range_max"); return NF_ERR_INVALID; }
+    if (d->rqs_min_bin_size * d->rqs_bins > d->rqs_range_max - d->rqs_range_min) {
+      set_error("rqs_min_bin_size * bins exceeds the range"); return NF_ERR_INVALID;
+    }
+    if (!(d->rqs_min_knot_slope < 1.f) || !(d->rqs_min_knot_slope > 0.f)) {
+      set_error("rqs_min_knot_slope must be in (0,1)"); return NF_ERR_INVALID;
+    }
+  }
+  return NF_OK;
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+struct nf_flow {
+  nf_flow_desc desc;
+  int device = 0;
+  int path = PATH_GENERIC;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_weights = false;
+  size_t weight_count = 0;
+  float* d_wimg = nullptr;  // path-specific packed weights
+  // staging for NF_MEM_HOST calls and for chains longer than one launch
+  float *d_x = nullptr, *d_y = nullptr, *d_ld = nullptr, *d_lp = nullptr;
+  long long stage_rows = 0;
+  double* d_block_sums = nullptr;
+  double* d_sum = nullptr;
+  double* h_ring = nullptr;  // pinned, NF_NLL_SLOTS
+  long long ring_rows[NF_NLL_SLOTS];
+  nf_comm* comm = nullptr;
+};
+
+namespace nf {
+
+static int ensure_stage(nf_flow* f, long long rows) {
+  if (rows <= f->stage_rows) return NF_OK;
+  const int D = f->desc.event_dim;
+  if (f->d_x) { hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp); }
+  f->d_x = f->d_y = f->d_ld = f->d_lp = nullptr;
+  f->stage_rows = 0;
+  NF_HIP(hipMalloc(&f->d_x, sizeof(float) * rows * D));
+  NF_HIP(hipMalloc(&f->d_y, sizeof(float) * rows * D));
+  NF_HIP(hipMalloc(&f->d_ld, sizeof(float) * rows));
+  NF_HIP(hipMalloc(&f->d_lp, sizeof(float) * rows));
+  f->stage_rows = rows;
+  return NF_OK;
+}
+
+static void direction_flags(int direction, int* descending, int* inverse_op) {
+  switch (direction) {
+    case NF_DIR_CHAIN_FORWARD: *descending = 1; *inverse_op = 0; break;
+    case NF_DIR_CHAIN_INVERSE: *descending = 0; *inverse_op = 1; break;
+    case NF_DIR_FIRST_TO_LAST_FORWARD: *descending = 0; *inverse_op = 0; break;
+    default: *descending = 1; *inverse_op = 1; break;
+  }
+}
+
+// Enqueue a chain walk on device pointers.  out_grid = number of block sums written.
+static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
+  ChainIO io = io_in;
+  io.base = f->desc.base;
+  if (f->path == PATH_SPLIT2D_SMALL) {
+    return split2d::launch(f->d_wimg, f->desc.hidden[0], f->desc.activation,
+                           f->desc.first_mask_parity, io, f->stream, out_grid);
+  }
+  if (f->path == PATH_AFFINE2D_H64) {
+    const int nlay = io.layer_end - io.layer_begin;
+    if (nlay <= affine2d::kMaxResidentLayers)
+      return affine2d::launch(f->d_wimg, f->desc.first_mask_parity, io, 0, f->stream, out_grid);
+    // more layers than fit in LDS: several launches, state carried in device scratch
+    NF_TRY(ensure_stage(f, io.rows));
+    const float* cur_x = io.x;
+    const float* cur_ld = io.logdet_in;
+    int done = 0;
+    while (done < nlay) {
+      const int n = std::min(affine2d::kMaxResidentLayers, nlay - done);
+      const bool last = done + n == nlay;
+      ChainIO seg = io;
+      if (io.descending) { seg.layer_end = io.layer_end - done; seg.layer_begin = seg.layer_end - n; }
+      else { seg.layer_begin = io.layer_begin + done; seg.layer_end = seg.layer_begin + n; }
+      seg.x = cur_x;
+      seg.logdet_in = cur_ld;
+      if (!last) {
+        seg.y = f->d_y; seg.logdet_out = f->d_ld; seg.logprob_out = nullptr;
+        seg.block_sums = nullptr; seg.add_base = 0;
+      }
+      NF_TRY(affine2d::launch(f->d_wimg, f->desc.first_mask_parity, seg, 0, f->stream, out_grid));
+      cur_x = f->d_y;
+      cur_ld = f->d_ld;
+      done += n;
+    }
+    return NF_OK;
+  }
+  set_error("flow configuration (kind %d, D=%d, %d hidden layers) has no kernel in this build yet",
+            f->desc.kind, f->desc.event_dim, f->desc.num_hidden);
+  return NF_ERR_UNSUPPORTED;
+}
+
+static int check_ready(nf_flow* f, const void* x, long long rows) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  if (!f->have_weights) { set_error("nf_flow_set_weights has not been called"); return NF_ERR_STATE; }
+  if (rows < 0) { set_error("rows must be >= 0"); return NF_ERR_INVALID; }
+  if (rows > 0 && !x) { set_error("x is NULL"); return NF_ERR_INVALID; }
+  return NF_OK;
+}
+
+static int check_device_ptr(const void* p, const char* name) {
+  if (p && (reinterpret_cast<uintptr_t>(p) & 15)) {
+    set_error("device pointer %s must be 16-byte aligned", name);
+    return NF_ERR_INVALID;
+  }
+  return NF_OK;
+}
+
+}  // namespace nf
+
+extern "C" {
+
+int nf_abi_version(void) { return NF_ABI_VERSION; }
+
+const char* nf_last_error(void) { return g_last_error.c_str(); }
+
+int nf_device_count(int* out_count) {
+  if (!out_count) { set_error("out_count is NULL"); return NF_ERR_INVALID; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  *out_count = n;
+  return NF_OK;
+}
+
+int nf_set_device(int device) { NF_HIP(hipSetDevice(device)); return NF_OK; }
+
+int nf_device_name(int device, char* buf, size_t buf_len) {
+  if (!buf || buf_len == 0) { set_error("buf is NULL"); return NF_ERR_INVALID; }
+  hipDeviceProp_t prop;
+  NF_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return NF_OK;
+}
+
+int nf_device_synchronize(void) { NF_HIP(hipDeviceSynchronize()); return NF_OK; }
+
+int nf_malloc(void** out_ptr, size_t bytes) {
+  if (!out_ptr) { set_error("out_ptr is NULL"); return NF_ERR_INVALID; }
+  *out_ptr = nullptr;
+  NF_HIP(hipMalloc(out_ptr, bytes ? bytes : 16));
+  return NF_OK;
+}
+int nf_free(void* ptr) { if (ptr) NF_HIP(hipFree(ptr)); return NF_OK; }
+int nf_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  NF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return NF_OK;
+}
+int nf_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  NF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return NF_OK;
+}
+
+int nf_flow_weight_count(const nf_flow_desc* desc, size_t* out_count) {
+  NF_TRY(validate_desc(desc));
+  if (!out_count) { set_error("out_count is NULL"); return NF_ERR_INVALID; }
+  std::vector<int> in, out;
+  linear_shapes(*desc, in, out);
+  size_t per_layer = 0;
+  for (size_t j = 0; j < in.size(); ++j) per_layer += (size_t)in[j] * out[j] + out[j];
+  *out_count = per_layer * desc->num_layers;
+  return NF_OK;
+}
+
+int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
+  if (!out_flow) { set_error("out_flow is NULL"); return NF_ERR_INVALID; }
+  *out_flow = nullptr;
+  NF_TRY(validate_desc(desc));
+  int ndev = 0;
+  nf_device_count(&ndev);
+  if (ndev == 0) { set_error("no HIP device visible: libnf_hip has no CPU fallback"); return NF_ERR_NO_DEVICE; }
+  nf_flow* f = new (std::nothrow) nf_flow();
+  if (!f) { set_error("out of host memory"); return NF_ERR_INVALID; }
+  f->desc = *desc;
+  nf_flow_weight_count(desc, &f->weight_count);
+  const nf_flow_desc& d = f->desc;
+  if (d.kind == NF_KIND_AFFINE_MASKED && d.event_dim == 2 && d.num_hidden == 2 &&
+      d.hidden[0] == 64 && d.hidden[1] == 64 && d.activation == NF_ACT_RELU)
+    f->path = PATH_AFFINE2D_H64;
+  else if (d.kind == NF_KIND_AFFINE_SPLIT && d.event_dim == 2 && d.num_hidden == 1 &&
+           d.hidden[0] <= split2d::kMaxHidden)
+    f->path = PATH_SPLIT2D_SMALL;
+  else
+    f->path = PATH_GENERIC;
+  int s = NF_OK;
+  do {
+    if (hipGetDevice(&f->device) != hipSuccess) { s = hip_fail(hipGetLastError(), "hipGetDevice", __FILE__, __LINE__); break; }
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&f->ev0)) != hipSuccess || (e = hipEventCreate(&f->ev1)) != hipSuccess ||
+        (e = hipMalloc(&f->d_block_sums, sizeof(double) * 4096)) != hipSuccess ||
+        (e = hipMalloc(&f->d_sum, sizeof(double) * NF_NLL_SLOTS)) != hipSuccess ||
+        (e = hipHostMalloc(&f->h_ring, sizeof(double) * NF_NLL_SLOTS, hipHostMallocDefault)) != hipSuccess) {
+      s = hip_fail(e, "flow resources", __FILE__, __LINE__);
+      break;
+    }
+  } while (0);
+  if (s != NF_OK) { nf_flow_destroy(f); return s; }
+  memset(f->ring_rows, 0, sizeof(f->ring_rows));
+  *out_flow = f;
+  return NF_OK;
+}
+
+void nf_flow_destroy(nf_flow* f) {
+  if (!f) return;
+  if (f->stream) hipStreamSynchronize(f->stream);
+  hipFree(f->d_wimg);
+  hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp);
+  hipFree(f->d_block_sums); hipFree(f->d_sum);
+  if (f->h_ring) hipHostFree(f->h_ring);
+  if (f->ev0) hipEventDestroy(f->ev0);
+  if (f->ev1) hipEventDestroy(f->ev1);
+  if (f->stream) hipStreamDestroy(f->stream);
+  delete f;
+}
+
+int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  if (!packed) { set_error("packed is NULL"); return NF_ERR_INVALID; }
+  if (count != f->weight_count) {
+    set_error("expected %zu float32 weights for this flow, got %zu", f->weight_count, count);
+    return NF_ERR_INVALID;
+  }
+  const nf_flow_desc& d = f->desc;
+  std::vector<int> in, out;
+  linear_shapes(d, in, out);
+  size_t per_layer = 0;
+  for (size_t j = 0; j < in.size(); ++j) per_layer += (size_t)in[j] * out[j] + out[j];
+  std::vector<float> img;
+  if (f->path == PATH_AFFINE2D_H64) {
+    img.resize((size_t)d.num_layers * affine2d::kLayerFloats);
+    for (int l = 0; l < d.num_layers; ++l) {
+      const float* W1 = packed + per_layer * l;
+      const float* b1 = W1 + 2 * 64;
+      const float* W2 = b1 + 64;
+      const float* b2 = W2 + 64 * 64;
+      const float* W3 = b2 + 64;
+      const float* b3 = W3 + 64 * 2;
+      const int cond_dim = (d.first_mask_parity + l) & 1;
+      affine2d::pack_layer(W1, b1, W2, b2, W3, b3, cond_dim, img.data() + (size_t)l * affine2d::kLayerFloats);
+    }
+  } else if (f->path == PATH_SPLIT2D_SMALL) {
+    // W0[1][H], b0[H], W1[H][2], b1[2] is already the kernel's order
+    img.assign(packed, packed + count);
+  } else {
+    set_error("flow configuration (kind %d, D=%d, %d hidden layers) has no kernel in this build yet",
+              d.kind, d.event_dim, d.num_hidden);
+    return NF_ERR_UNSUPPORTED;
+  }
+  NF_HIP(hipStreamSynchronize(f->stream));
+  if (f->d_wimg) { hipFree(f->d_wimg); f->d_wimg = nullptr; }
+  NF_HIP(hipMalloc(&f->d_wimg, img.size() * sizeof(float)));
+  NF_HIP(hipMemcpy(f->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  f->have_weights = true;
+  return NF_OK;
+}
+
+int nf_flow_kernel_name(const nf_flow* f, char* buf, size_t buf_len) {
+  if (!f || !buf || !buf_len) { set_error("bad argument"); return NF_ERR_INVALID; }
+  snprintf(buf, buf_len, "%s", path_name(f->path));
+  return NF_OK;
+}
+
+int nf_flow_synchronize(nf_flow* f) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  NF_HIP(hipStreamSynchronize(f->stream));
+  return NF_OK;
+}
+
+int nf_chain_apply(nf_flow* f, int direction, int layer_begin, int layer_end, const float* x,
+                   int64_t rows, float* y, float* logdet, int mem) {
+  NF_TRY(check_ready(f, x, rows));
+  if (direction < NF_DIR_CHAIN_FORWARD || direction > NF_DIR_LAST_TO_FIRST_INVERSE) {
+    set_error("unknown direction %d", direction); return NF_ERR_INVALID;
+  }
+  if (layer_begin < 0 || layer_end > f->desc.num_layers || layer_begin >= layer_end) {
+    set_error("layer range [%d,%d) outside the chain's %d layers", layer_begin, layer_end, f->desc.num_layers);
+    return NF_ERR_INVALID;
+  }
+  if (rows == 0) return NF_OK;
+  const int D = f->desc.event_dim;
+  ChainIO io;
+  memset(&io, 0, sizeof(io));
+  io.rows = rows;
+  io.layer_begin = layer_begin;
+  io.layer_end = layer_end;
+  direction_flags(direction, &io.descending, &io.inverse_op);
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(check_device_ptr(x, "x")); NF_TRY(check_device_ptr(y, "y")); NF_TRY(check_device_ptr(logdet, "logdet"));
+    io.x = x; io.y = y; io.logdet_out = logdet;
+    return run_chain_device(f, io, nullptr);
+  }
+  NF_TRY(ensure_stage(f, rows));
+  // a long chain uses d_y / d_ld as its own scratch, so stage outputs there too
+  NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
+  io.x = f->d_x; io.y = y ? f->d_y : nullptr; io.logdet_out = logdet ? f->d_ld : nullptr;
+  NF_TRY(run_chain_device(f, io, nullptr));
+  if (y) NF_HIP(hipMemcpyAsync(y, f->d_y, sizeof(float) * rows * D, hipMemcpyDeviceToHost, f->stream));
+  if (logdet) NF_HIP(hipMemcpyAsync(logdet, f->d_ld, sizeof(float) * rows, hipMemcpyDeviceToHost, f->stream));
+  NF_HIP(hipStreamSynchronize(f->stream));
+  return NF_OK;
+}
+
+static int enqueue_log_prob(nf_flow* f, const float* x_dev, long long rows, float* lp_dev,
+                            bool want_sum, int* out_grid) {
+  ChainIO io;
+  memset(&io, 0, sizeof(io));
+  io.rows = rows;
+  io.layer_begin = 0;
+  io.layer_end = f->desc.num_layers;
+  direction_flags(f->desc.kind == NF_KIND_AFFINE_SPLIT ? NF_DIR_LAST_TO_FIRST_INVERSE : NF_DIR_CHAIN_FORWARD,
+                  &io.descending, &io.inverse_op);
+  io.x = x_dev;
+  io.logprob_out = lp_dev;
+  io.block_sums = want_sum ? f->d_block_sums : nullptr;
+  io.add_base = 1;
+  return run_chain_device(f, io, out_grid);
+}
+
+int nf_log_prob(nf_flow* f, const float* x, int64_t rows, float* out_log_prob, int mem) {
+  NF_TRY(check_ready(f, x, rows));
+  if (!out_log_prob && rows > 0) { set_error("out_log_prob is NULL"); return NF_ERR_INVALID; }
+  if (rows == 0) return NF_OK;
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(check_device_ptr(x, "x")); NF_TRY(check_device_ptr(out_log_prob, "out_log_prob"));
+    return enqueue_log_prob(f, x, rows, out_log_prob, false, nullptr);
+  }
+  NF_TRY(ensure_stage(f, rows));
+  const int D = f->desc.event_dim;
+  NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
+  NF_TRY(enqueue_log_prob(f, f->d_x, rows, f->d_lp, false, nullptr));
+  NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows, hipMemcpyDeviceToHost, f->stream));
+  NF_HIP(hipStreamSynchronize(f->stream));
+  return NF_OK;
+}
+
+int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t rows_global,
+                   float* out_log_prob_dev, int slot) {
+  NF_TRY(check_ready(f, x_dev, rows_local));
+  if (slot < 0 || slot >= NF_NLL_SLOTS) { set_error("slot must be 0..%d", NF_NLL_SLOTS - 1); return NF_ERR_INVALID; }
+  if (rows_global < rows_local || rows_global < 1) { set_error("rows_global must be >= rows_local and >= 1"); return NF_ERR_INVALID; }
+  NF_TRY(check_device_ptr(x_dev, "x")); NF_TRY(check_device_ptr(out_log_prob_dev, "out_log_prob"));
+  int grid = 0;
+  if (rows_local > 0) {
+    NF_TRY(enqueue_log_prob(f, x_dev, rows_local, out_log_prob_dev, true, &grid));
+    NF_TRY(launch_sum_blocks(f->d_block_sums, grid, f->d_sum + slot, f->stream));
+  } else {
+    NF_HIP(hipMemsetAsync(f->d_sum + slot, 0, sizeof(double), f->stream));
+  }
+  if (f->comm) NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_sum + slot, f->stream));
+  NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  f->ring_rows[slot] = rows_global;
+  return NF_OK;
+}
+
+int nf_nll_result(nf_flow* f, int slot, double* out_nll) {
+  if (!f || !out_nll) { set_error("bad argument"); return NF_ERR_INVALID; }
+  if (slot < 0 || slot >= NF_NLL_SLOTS || f->ring_rows[slot] == 0) {
+    set_error("slot %d holds no result", slot); return NF_ERR_STATE;
+  }
+  *out_nll = -f->h_ring[slot] / (double)f->ring_rows[slot];
+  return NF_OK;
+}
+
+int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, float* out_log_prob,
+           double* out_nll, int mem) {
+  NF_TRY(check_ready(f, x, rows_local));
+  if (!out_nll) { set_error("out_nll is NULL"); return NF_ERR_INVALID; }
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(nf_nll_enqueue(f, x, rows_local, rows_global, out_log_prob, 0));
+    NF_HIP(hipStreamSynchronize(f->stream));
+    return nf_nll_result(f, 0, out_nll);
+  }
+  const int D = f->desc.event_dim;
+  if (rows_local > 0) {
+    NF_TRY(ensure_stage(f, rows_local));
+    NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows_local * D, hipMemcpyHostToDevice, f->stream));
+  }
+  NF_TRY(nf_nll_enqueue(f, f->d_x, rows_local, rows_global, out_log_prob ? f->d_lp : nullptr, 0));
+  if (out_log_prob && rows_local > 0)
+    NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows_local, hipMemcpyDeviceToHost, f->stream));
+  NF_HIP(hipStreamSynchronize(f->stream));
+  return nf_nll_result(f, 0, out_nll);
+}
+
+int nf_timer_start(nf_flow* f) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  NF_HIP(hipEventRecord(f->ev0, f->stream));
+  return NF_OK;
+}
+
+int nf_timer_stop(nf_flow* f, float* out_ms) {
+  if (!f || !out_ms) { set_error("bad argument"); return NF_ERR_INVALID; }
+  NF_HIP(hipEventRecord(f->ev1, f->stream));
+  NF_HIP(hipEventSynchronize(f->ev1));
+  NF_HIP(hipEventElapsedTime(out_ms, f->ev0, f->ev1));
+  return NF_OK;
+}
+
+int nf_flow_attach_comm(nf_flow* f, nf_comm* comm) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  f->comm = comm;
+  return NF_OK;
+}
+
+}  // extern "C"

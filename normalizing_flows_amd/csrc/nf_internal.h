@@ -1,0 +1,88 @@
+// Internal declarations shared by the translation units of libnf_hip.so.
+// Not part of the ABI (that is include/nf_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "nf_hip.h"
+
+namespace nf {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define NF_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t _e = (call);                                                 \
+    if (_e != hipSuccess) return ::nf::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define NF_TRY(call)        \
+  do {                      \
+    int _s = (call);        \
+    if (_s != NF_OK) return _s; \
+  } while (0)
+
+// ---- what every chain kernel is told ------------------------------------------
+struct ChainIO {
+  const float* x;          // [rows, D]
+  const float* logdet_in;  // [rows] or null (0)
+  float* y;                // [rows, D] or null
+  float* logdet_out;       // [rows] or null
+  float* logprob_out;      // [rows] or null: base log-density + logdet
+  double* block_sums;      // [gridDim.x] or null: per-block sum of logprob (float64)
+  long long rows;
+  int layer_begin, layer_end;  // walk layers [begin, end)
+  int descending;              // 1: end-1 .. begin, 0: begin .. end-1
+  int inverse_op;              // 1: x = (y - shift) * exp(-ls), logdet -= ls
+  int add_base;                // 1: logprob includes the base log-density
+  int base;                    // nf_base
+};
+
+// ---- path 1: masked affine coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2 ------
+namespace affine2d {
+// LDS / global image of ONE coupling layer, in floats.  Built on the host by
+// pack_layer() so that every MFMA operand is a plain contiguous LDS read.
+constexpr int kHidden = 64;
+constexpr int kA2 = 0;                  // [32 kstep][64 lane][2 mtile]  W2 as MFMA A operand
+constexpr int kW1B1 = 4096;             // [64 k][2]                      (w1[k], b1[k])
+constexpr int kB2 = kW1B1 + 128;        // [2 half][2 mtile][16 reg]      b2 in accumulator order
+constexpr int kW3 = kB2 + 64;           // [2 half][2 mtile][16 reg][2]   W3 rows in accumulator order
+constexpr int kB3 = kW3 + 128;          // [2] + 2 pad
+constexpr int kLayerFloats = kB3 + 4;   // 4420 floats = 17,680 B
+constexpr int kMaxResidentLayers = 9;   // 9 * 17,680 + 64 <= 160 KiB of LDS
+constexpr int kThreads = 512;           // 8 waves: two per SIMD
+
+// cond_dim: which of the two event dims feeds the conditioner in this layer.
+void pack_layer(const float* W1 /*[2][64]*/, const float* b1, const float* W2 /*[64][64]*/,
+                const float* b2, const float* W3 /*[64][2]*/, const float* b3, int cond_dim,
+                float* image /*[kLayerFloats]*/);
+
+// wimg holds the images of ALL layers of the flow, layer-major.
+int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid_cap,
+           hipStream_t stream, int* out_grid);
+int max_grid();  // blocks the launch uses at most (= size of block_sums needed)
+}  // namespace affine2d
+
+// ---- path 2: split-halves affine coupling (variant A), D = 2, MLP 1 -> H -> 2 ----
+namespace split2d {
+constexpr int kMaxHidden = 64;
+// per-layer device image: w0[H], b0[H], w1[H][2], b1[2]
+__host__ __device__ inline int layer_floats(int H) { return 4 * H + 2; }
+int launch(const float* wimg, int H, int activation, int first_flip, const ChainIO& io,
+           hipStream_t stream, int* out_grid);
+int max_grid();
+}  // namespace split2d
+
+// ---- float64 fixed-order reduction of per-block sums --------------------------
+int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream);
+
+// ---- RCCL (dlopen'ed) ---------------------------------------------------------
+int comm_allreduce_sum_f64(nf_comm* comm, double* dev_value, hipStream_t stream);
+
+}  // namespace nf

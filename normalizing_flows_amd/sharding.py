@@ -1,0 +1,86 @@
+"""Data-parallel evaluation: rows of the sample matrix are split over ranks, the
+only exchange is the sum of ONE float64.
+
+The reference is single-process (`-jnp.mean(log_prob.apply(params, batch))`,
+src/real_nvp_toy_densities.py:143,150); this is the multi-GPU form of that mean:
+
+    NLL = -(sum over ranks of sum_local(log_prob)) / rows_global
+
+On GPUs the all-reduce runs inside libnf_hip (RCCL over xGMI, on the flow's
+stream).  `ShardedNLL` takes any `allreduce_sum(float) -> float`, which is how the
+world_size-2 gloo tests drive the same host logic on CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+from . import _lib
+from ._lib import check
+
+
+def shard_rows(rows_global: int, world: int, rank: int, align: int = 2) -> Tuple[int, int]:
+    """Contiguous block [begin, end) of rank `rank`.  Blocks differ by at most
+    `align` rows and begin on a multiple of `align` (keeps 16-byte row alignment
+    for [rows, 2] float32 matrices); the last rank takes the remainder."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    if rows_global < 0:
+        raise ValueError("rows_global must be >= 0")
+    units = rows_global // align
+    base, extra = divmod(units, world)
+    begin_u = rank * base + min(rank, extra)
+    end_u = begin_u + base + (1 if rank < extra else 0)
+    begin, end = begin_u * align, end_u * align
+    if rank == world - 1:
+        end = rows_global
+    return begin, end
+
+
+class RcclComm:
+    """One RCCL communicator (one rank per GPU)."""
+
+    def __init__(self, world: int, rank: int, unique_id: bytes):
+        if len(unique_id) != _lib.NF_COMM_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        self.world, self.rank = world, rank
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, _lib.NF_COMM_ID_BYTES)
+        check(_lib.load().nf_comm_init_rank(C.byref(self._h), world, rank, buf))
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.NF_COMM_ID_BYTES)
+        check(_lib.load().nf_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, dist) -> "RcclComm":
+        """Rank 0 makes the id; the (CPU) process group carries it to the others."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(world, rank, box[0])
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().nf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class ShardedNLL:
+    """Host logic of the sharded mean, independent of who computes the local sum.
+
+    local_sum_fn(begin, end) -> float64 sum of log_prob over this rank's rows;
+    allreduce_sum(v) -> sum of v over all ranks.
+    """
+
+    def __init__(self, world: int, rank: int, allreduce_sum: Callable[[float], float]):
+        self.world, self.rank, self.allreduce_sum = world, rank, allreduce_sum
+
+    def nll(self, rows_global: int, local_sum_fn: Callable[[int, int], float]) -> float:
+        if rows_global < 1:
+            raise ValueError("NLL of an empty batch is undefined")
+        begin, end = shard_rows(rows_global, self.world, self.rank)
+        local = float(local_sum_fn(begin, end)) if end > begin else 0.0
+        return -self.allreduce_sum(local) / rows_global

@@ -1,0 +1,493 @@
+"""CPU oracle: NumPy restatement of the reference's coupling-flow log_prob path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in ``normalizing_flows_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker.
+
+PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+(SURVEY.md §4), and jax / distrax / haiku / tfp are not installed in this image,
+so the reference itself cannot be executed here.  This file restates
+
+* variant A from the reference source text (``src/real_nvp.py``), function by
+  function, and
+* variants B / C / D from the reference call sites
+  (``src/real_nvp_toy_densities.py``, ``src/maf_toy_densities.py``,
+  ``src/maf_mnist.py``) plus the published semantics of the third-party
+  libraries they call (distrax ~0.1.x, dm-haiku; un-pinned in
+  ``environment.yml:17-18``).  The rational-quadratic-spline details are
+  restated from the distrax source as published, unverified in-container.
+
+It is pinned instead by the known-answer tests of SURVEY.md §8c
+(``tests/test_oracle_kat.py``).
+
+Every function takes a ``dtype`` (np.float32 reproduces the reference's
+arithmetic type, np.float64 is the high-precision arbiter used for golden
+vectors).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+LEAKY_SLOPE = 0.01  # jax.nn.leaky_relu default negative_slope (src/real_nvp.py:167)
+
+
+# --------------------------------------------------------------------------
+# activations
+# --------------------------------------------------------------------------
+def relu(v):
+    return np.maximum(v, 0)
+
+
+def leaky_relu(v):
+    return np.where(v >= 0, v, v * v.dtype.type(LEAKY_SLOPE))
+
+
+_ACT = {"relu": relu, "leaky_relu": leaky_relu}
+
+
+# --------------------------------------------------------------------------
+# Variant A  --  src/real_nvp.py
+# --------------------------------------------------------------------------
+def a_shift_and_log_scale(net_params, x1, dtype=np.float64):
+    """src/real_nvp.py:161-171.  ``net_params = [[W,b], ..., [W_last,b_last]]``.
+
+    Hidden layers use leaky_relu, the last layer is linear and its two output
+    columns are (shift, log_scale).
+    """
+    act = np.asarray(x1, dtype)
+    for W, b in net_params[:-1]:
+        act = leaky_relu(act @ np.asarray(W, dtype) + np.asarray(b, dtype))
+    W, b = net_params[-1]
+    out = act @ np.asarray(W, dtype) + np.asarray(b, dtype)
+    half = out.shape[1] // 2
+    return out[:, :half], out[:, half:]
+
+
+def _a_split(v, flip):
+    d = v.shape[-1] // 2
+    lo, hi = v[:, :d], v[:, d:]
+    return (hi, lo) if flip else (lo, hi)
+
+
+def _a_join(keep, moved, flip):
+    return np.concatenate([moved, keep] if flip else [keep, moved], axis=-1)
+
+
+def a_forward_layer(net_params, x, flip, dtype=np.float64):
+    """src/real_nvp.py:71-101 (generative direction of one coupling layer)."""
+    x = np.asarray(x, dtype)
+    x1, x2 = _a_split(x, flip)
+    shift, log_scale = a_shift_and_log_scale(net_params, x1, dtype)
+    y2 = x2 * np.exp(log_scale) + shift
+    return _a_join(x1, y2, flip)
+
+
+def a_inverse_layer(net_params, y, flip, dtype=np.float64):
+    """src/real_nvp.py:104-134; returns (x, log_scale)."""
+    y = np.asarray(y, dtype)
+    y1, y2 = _a_split(y, flip)
+    shift, log_scale = a_shift_and_log_scale(net_params, y1, dtype)
+    x2 = (y2 - shift) * np.exp(-log_scale)
+    return _a_join(y1, x2, flip), log_scale
+
+
+def a_base_log_prob(x, dtype=np.float64):
+    """src/real_nvp.py:57-68: MultivariateNormalDiag(0, I).log_prob."""
+    x = np.asarray(x, dtype)
+    d = x.shape[-1]
+    return -0.5 * np.sum(x * x, axis=-1) - dtype(0.5 * d * math.log(2.0 * math.pi))
+
+
+def a_log_prob_chain(params, flips, y, dtype=np.float64):
+    """src/real_nvp.py:137-158, 251-283.
+
+    The closure chain evaluates the LAST layer's inverse first and the base
+    density last; every layer contributes ``-sum(log_scale)``.
+    """
+    v = np.asarray(y, dtype)
+    total = np.zeros(v.shape[0], dtype)
+    for net_params, flip in zip(reversed(params), reversed(flips)):
+        v, log_scale = a_inverse_layer(net_params, v, flip, dtype)
+        total = total - np.sum(log_scale, axis=-1)
+    return a_base_log_prob(v, dtype) + total
+
+
+def a_sample_chain_from_z(params, flips, z, dtype=np.float64):
+    """src/real_nvp.py:228-248 with the base sample ``z`` supplied by the host."""
+    v = np.asarray(z, dtype)
+    for net_params, flip in zip(params, flips):
+        v = a_forward_layer(net_params, v, flip, dtype)
+    return v
+
+
+def a_nll(params, flips, y, dtype=np.float64):
+    """src/real_nvp.py:292-293."""
+    return -np.mean(a_log_prob_chain(params, flips, y, dtype))
+
+
+# --------------------------------------------------------------------------
+# haiku-style conditioner used by B / C / D
+# --------------------------------------------------------------------------
+def conditioner_apply(layer_params, masked_x, dtype=np.float64):
+    """hk.Sequential([Flatten, MLP(hidden, activate_final=True), Linear(P)]).
+
+    ``layer_params = [(W0,b0), ..., (W_last,b_last)]``; all but the last are
+    followed by relu (haiku default activation), the last is the zero-initialised
+    hk.Linear (src/real_nvp_toy_densities.py:56-71, src/maf_mnist.py:34-49).
+    ``masked_x`` is already flattened to [B, D].
+    """
+    act = np.asarray(masked_x, dtype)
+    for W, b in layer_params[:-1]:
+        act = relu(act @ np.asarray(W, dtype) + np.asarray(b, dtype))
+    W, b = layer_params[-1]
+    return act @ np.asarray(W, dtype) + np.asarray(b, dtype)
+
+
+def alternating_masks(event_size: int, num_layers: int, first_parity: int = 1):
+    """src/real_nvp_toy_densities.py:80-82,102: ``arange(D) % 2`` then flipped
+    (logical_not) after every layer.  True = pass-through, visible to the
+    conditioner.  ``first_parity=1`` is the reference's value."""
+    m = (np.arange(event_size) % 2) == first_parity
+    out = []
+    for _ in range(num_layers):
+        out.append(m.copy())
+        m = ~m
+    return out
+
+
+# --------------------------------------------------------------------------
+# distrax.ScalarAffine
+# --------------------------------------------------------------------------
+def scalar_affine_fwd(x, shift, log_scale):
+    return np.exp(log_scale) * x + shift, np.broadcast_to(log_scale, np.broadcast(x, log_scale).shape)
+
+
+def scalar_affine_inv(y, shift, log_scale):
+    return np.exp(-log_scale) * (y - shift), np.broadcast_to(-log_scale, np.broadcast(y, log_scale).shape)
+
+
+# --------------------------------------------------------------------------
+# distrax.RationalQuadraticSpline
+# --------------------------------------------------------------------------
+def _softmax(v):
+    v = v - np.max(v, axis=-1, keepdims=True)
+    e = np.exp(v)
+    return e / np.sum(e, axis=-1, keepdims=True)
+
+
+def _softplus(v):
+    return np.logaddexp(v, v.dtype.type(0))
+
+
+def rqs_knots(params, range_min, range_max, min_bin_size=1e-4, min_knot_slope=1e-4,
+              dtype=np.float64):
+    """Normalise raw conditioner outputs [..., 3K+1] into knots.
+
+    Returns (x_pos, y_pos, slopes), each [..., K+1].  boundary_slopes =
+    'unconstrained' (the distrax default, which is what the reference uses).
+    """
+    p = np.asarray(params, dtype)
+    n = p.shape[-1]
+    if n % 3 != 1 or n < 4:
+        raise ValueError(f"spline needs 3K+1 parameters, got {n}")
+    if not range_min < range_max:
+        raise ValueError("range_min must be below range_max")
+    K = (n - 1) // 3
+    total = dtype(range_max - range_min)
+    if K * min_bin_size > total:
+        raise ValueError("bins do not fit the range")
+    mb = dtype(min_bin_size)
+    widths = _softmax(p[..., :K]) * (total - K * mb) + mb
+    heights = _softmax(p[..., K:2 * K]) * (total - K * mb) + mb
+    lo = np.full(p.shape[:-1] + (1,), range_min, dtype)
+    hi = np.full(p.shape[:-1] + (1,), range_max, dtype)
+    x_pos = np.concatenate([lo, dtype(range_min) + np.cumsum(widths[..., :-1], axis=-1), hi], axis=-1)
+    y_pos = np.concatenate([lo, dtype(range_min) + np.cumsum(heights[..., :-1], axis=-1), hi], axis=-1)
+    ms = dtype(min_knot_slope)
+    offset = np.log(np.exp(dtype(1) - ms) - dtype(1))
+    slopes = _softplus(p[..., 2 * K:] + offset) + ms
+    return x_pos, y_pos, slopes
+
+
+def _pick_bin(v, pos):
+    """Index of the bin with pos[k] <= v < pos[k+1]; bin 0 when none matches."""
+    inside = (v[..., None] >= pos[..., :-1]) & (v[..., None] < pos[..., 1:])
+    any_in = inside.any(axis=-1)
+    idx = np.argmax(inside, axis=-1)
+    return np.where(any_in, idx, 0)
+
+
+def _take(a, idx):
+    return np.take_along_axis(a, idx[..., None], axis=-1)[..., 0]
+
+
+def rqs_fwd(x, x_pos, y_pos, slopes):
+    """Forward spline + log|dy/dx| with linear tails outside the range."""
+    dt = x_pos.dtype
+    x = np.asarray(x, dt)
+    one, two = dt.type(1), dt.type(2)
+    k = _pick_bin(x, x_pos)
+    xl, xr = _take(x_pos, k), _take(x_pos, k + 1)
+    yl, yr = _take(y_pos, k), _take(y_pos, k + 1)
+    sl, sr = _take(slopes, k), _take(slopes, k + 1)
+    w = xr - xl
+    h = yr - yl
+    delta = h / w
+    z = np.clip((x - xl) / w, 0, 1)
+    zz = z * z
+    z1mz = z - zz
+    omz2 = (one - z) ** 2
+    st = sr + sl - two * delta
+    num = h * (delta * zz + sl * z1mz)
+    den = delta + st * z1mz
+    y = yl + num / den
+    logdet = two * np.log(delta) + np.log(sr * zz + two * delta * z1mz + sl * omz2) - two * np.log(den)
+    below = x <= x_pos[..., 0]
+    above = x >= x_pos[..., -1]
+    y = np.where(below, (x - x_pos[..., 0]) * slopes[..., 0] + y_pos[..., 0], y)
+    y = np.where(above, (x - x_pos[..., -1]) * slopes[..., -1] + y_pos[..., -1], y)
+    logdet = np.where(below, np.log(slopes[..., 0]), logdet)
+    logdet = np.where(above, np.log(slopes[..., -1]), logdet)
+    return y, logdet
+
+
+def rqs_inv(y, x_pos, y_pos, slopes):
+    """Inverse spline (quadratic root) + log|dx/dy|."""
+    dt = x_pos.dtype
+    y = np.asarray(y, dt)
+    one, two, four = dt.type(1), dt.type(2), dt.type(4)
+    k = _pick_bin(y, y_pos)
+    xl, xr = _take(x_pos, k), _take(x_pos, k + 1)
+    yl, yr = _take(y_pos, k), _take(y_pos, k + 1)
+    sl, sr = _take(slopes, k), _take(slopes, k + 1)
+    w = xr - xl
+    h = yr - yl
+    delta = h / w
+    u = np.clip((y - yl) / h, 0, 1)
+    st = sr + sl - two * delta
+    c = -delta * u
+    b = sl - st * u
+    a = delta - b
+    z = -two * c / (b + np.sqrt(b * b - four * a * c))
+    z = np.clip(z, 0, 1)
+    x = w * z + xl
+    zz = z * z
+    z1mz = z - zz
+    omz2 = (one - z) ** 2
+    den = delta + st * z1mz
+    logdet = -two * np.log(delta) - np.log(sr * zz + two * delta * z1mz + sl * omz2) + two * np.log(den)
+    below = y <= y_pos[..., 0]
+    above = y >= y_pos[..., -1]
+    x = np.where(below, (y - y_pos[..., 0]) / slopes[..., 0] + x_pos[..., 0], x)
+    x = np.where(above, (y - y_pos[..., -1]) / slopes[..., -1] + x_pos[..., -1], x)
+    logdet = np.where(below, -np.log(slopes[..., 0]), logdet)
+    logdet = np.where(above, -np.log(slopes[..., -1]), logdet)
+    return x, logdet
+
+
+# --------------------------------------------------------------------------
+# distrax.MaskedCoupling with the two inner bijectors the reference uses
+# --------------------------------------------------------------------------
+class FlowSpec:
+    """Plain description of a B / C / D flow (what the reference's
+    ``make_flow_model`` builds).
+
+    kind            'affine' (B: ScalarAffine, conditioner emits 2 numbers that
+                    broadcast over every event dim, src/real_nvp_toy_densities.py:84-86)
+                    or 'rqs' (C/D: conditioner emits D*(3K+1), reshaped [D, 3K+1])
+    event_size      D (flattened event)
+    layers          list of conditioner parameter lists [(W,b), ...]
+    masks           list of bool[D], True = pass-through
+    base            'normal' (Independent(Normal(0,1))) or 'uniform01'
+    """
+
+    def __init__(self, kind, event_size, layers, masks, base="normal",
+                 num_bins=0, range_min=0.0, range_max=1.0,
+                 min_bin_size=1e-4, min_knot_slope=1e-4):
+        self.kind = kind
+        self.event_size = int(event_size)
+        self.layers = layers
+        self.masks = masks
+        self.base = base
+        self.num_bins = int(num_bins)
+        self.range_min = float(range_min)
+        self.range_max = float(range_max)
+        self.min_bin_size = float(min_bin_size)
+        self.min_knot_slope = float(min_knot_slope)
+
+
+def coupling_layer(spec: FlowSpec, l: int, v, inverse: bool, dtype=np.float64):
+    """One MaskedCoupling.forward_and_log_det / inverse_and_log_det (row b3)."""
+    v = np.asarray(v, dtype)
+    mask = spec.masks[l]
+    masked = np.where(mask, v, dtype(0))
+    raw = conditioner_apply(spec.layers[l], masked, dtype)
+    if spec.kind == "affine":
+        shift, log_scale = raw[:, :1], raw[:, 1:2]  # split(params, 2, axis=-1)
+        if inverse:
+            out, ld = scalar_affine_inv(v, shift, log_scale)
+        else:
+            out, ld = scalar_affine_fwd(v, shift, log_scale)
+    elif spec.kind == "rqs":
+        P = 3 * spec.num_bins + 1
+        raw = raw.reshape(v.shape[0], spec.event_size, P)
+        xp, yp, sl = rqs_knots(raw, spec.range_min, spec.range_max,
+                               spec.min_bin_size, spec.min_knot_slope, dtype)
+        out, ld = (rqs_inv if inverse else rqs_fwd)(v, xp, yp, sl)
+    else:
+        raise ValueError(spec.kind)
+    out = np.where(mask, v, out)
+    logdet = np.sum(np.where(mask, dtype(0), ld), axis=-1)
+    return out.astype(dtype), logdet.astype(dtype)
+
+
+def chain_forward(spec: FlowSpec, v, dtype=np.float64):
+    """distrax.Chain(layers).forward_and_log_det: LAST layer first (row b5)."""
+    v = np.asarray(v, dtype)
+    total = np.zeros(v.shape[0], dtype)
+    for l in reversed(range(len(spec.layers))):
+        v, ld = coupling_layer(spec, l, v, False, dtype)
+        total = total + ld
+    return v, total
+
+
+def chain_inverse(spec: FlowSpec, v, dtype=np.float64):
+    """distrax.Chain(layers).inverse_and_log_det: layer 0 first."""
+    v = np.asarray(v, dtype)
+    total = np.zeros(v.shape[0], dtype)
+    for l in range(len(spec.layers)):
+        v, ld = coupling_layer(spec, l, v, True, dtype)
+        total = total + ld
+    return v, total
+
+
+def base_log_prob(spec: FlowSpec, z, dtype=np.float64):
+    z = np.asarray(z, dtype)
+    if spec.base == "normal":
+        # Independent(Normal(0,1)): sum_d(-x^2/2 - log(2 pi)/2)
+        return np.sum(-0.5 * z * z - dtype(0.5 * math.log(2.0 * math.pi)), axis=-1)
+    if spec.base == "uniform01":
+        inside = np.all((z >= 0) & (z <= 1), axis=-1)
+        return np.where(inside, dtype(0), dtype(-np.inf))
+    raise ValueError(spec.base)
+
+
+def log_prob(spec: FlowSpec, x, dtype=np.float64):
+    """Transformed(base, Inverse(Chain(layers))).log_prob (rows b5, b6)."""
+    z, ld = chain_forward(spec, x, dtype)
+    return base_log_prob(spec, z, dtype) + ld
+
+
+def sample_from_z(spec: FlowSpec, z, dtype=np.float64):
+    """Transformed.sample with the base draw supplied: Chain.inverse(z)."""
+    return chain_inverse(spec, z, dtype)[0]
+
+
+def nll(spec: FlowSpec, x, dtype=np.float64):
+    """loss_fn / eval_fn: -mean(log_prob) (src/real_nvp_toy_densities.py:139-151)."""
+    return -np.mean(log_prob(spec, x, dtype))
+
+
+# --------------------------------------------------------------------------
+# synthetic weights and inputs
+# --------------------------------------------------------------------------
+def _trunc_normal(rng, shape, std):
+    out = rng.standard_normal(shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * std).astype(np.float32)
+
+
+def make_conditioner_weights(layer_index, in_size, hidden, out_size, final_std=0.05, seed=534):
+    """Hidden layers: TruncNormal(+-2 sigma), sigma = 1/sqrt(fan_in), b = 0 (haiku
+    MLP default).  Final layer N(0, final_std^2) weights and biases (non-zero so
+    the flow is not the identity; final_std=0 gives the reference's zero init).
+    Seed = 534 + layer index."""
+    rng = np.random.Generator(np.random.PCG64(seed + layer_index))
+    sizes = [in_size] + list(hidden)
+    out = []
+    for fi, fo in zip(sizes[:-1], sizes[1:]):
+        out.append((_trunc_normal(rng, (fi, fo), 1.0 / math.sqrt(fi)), np.zeros(fo, np.float32)))
+    W = (rng.standard_normal((sizes[-1], out_size)) * final_std).astype(np.float32)
+    b = (rng.standard_normal(out_size) * final_std).astype(np.float32)
+    out.append((W, b))
+    return out
+
+
+def make_affine_spec(num_layers=8, event_size=2, hidden=(64, 64), final_std=0.05,
+                     first_parity=1, seed=534):
+    layers = [make_conditioner_weights(l, event_size, hidden, 2, final_std, seed)
+              for l in range(num_layers)]
+    return FlowSpec("affine", event_size, layers,
+                    alternating_masks(event_size, num_layers, first_parity), "normal")
+
+
+def make_rqs_spec(num_layers=8, event_size=2, hidden=(64, 64), num_bins=12,
+                  range_min=-8.0, range_max=8.0, base="normal", final_std=0.05,
+                  first_parity=1, seed=534):
+    P = 3 * num_bins + 1
+    layers = [make_conditioner_weights(l, event_size, hidden, event_size * P, final_std, seed)
+              for l in range(num_layers)]
+    return FlowSpec("rqs", event_size, layers,
+                    alternating_masks(event_size, num_layers, first_parity), base,
+                    num_bins, range_min, range_max)
+
+
+def make_a_params(num_layers=8, sizes=(1, 4, 2), seed=534):
+    """Variant A weights: W ~ 0.1 N(0,1), b = 0, distinct seed per layer
+    (src/real_nvp.py:187-194 reuses one key; SURVEY §8d asks for distinct)."""
+    params, flips = [], []
+    flip = False
+    for l in range(num_layers):
+        rng = np.random.Generator(np.random.PCG64(seed + l))
+        net = []
+        for m, n in zip(sizes[:-1], sizes[1:]):
+            net.append([(rng.standard_normal((m, n)) * 0.1).astype(np.float32),
+                        np.zeros(n, np.float32)])
+        params.append(net)
+        flips.append(flip)
+        flip = not flip
+    return params, flips
+
+
+def _w1(z):
+    return np.sin(2.0 * np.pi * z / 4.0)
+
+
+def make_inputs(density: str, n: int, seed: int = 2123) -> np.ndarray:
+    """Synthetic [n,2] float32 rows with the distributions of the reference's
+    generators (src/densities/*.py); NumPy Philox instead of JAX threefry."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    if density == "banana":  # src/densities/banana.py:37-41
+        x2 = rng.normal(0.0, math.sqrt(3.0), n)
+        x1 = rng.normal(x2 ** 2 / 3.0 - 2.0, math.sqrt(3.0) / 2.0)
+        rows = np.stack([x1, x2], -1)
+    elif density == "energy1":  # src/densities/energies.py:47-66
+        z = rng.normal(0.0, 2.0, n)
+        mu = 2.0 - z ** 2 / 32.0
+        c = rng.integers(0, 2, n) * 2 - 1
+        v = rng.normal(c * mu, 0.3)
+        rows = np.stack([v, z], -1)
+    elif density in ("energy2", "energy3", "energy4"):  # :69-127
+        x1 = rng.uniform(-1.5 * np.pi, 1.5 * np.pi, n)
+        m = _w1(x1)
+        pick = rng.integers(0, 2, n).astype(bool)
+        if density == "energy3":
+            m = np.where(pick, m - 3.0 * np.exp(-0.5 * ((x1 - 1.0) / 0.6) ** 2), m)
+        elif density == "energy4":
+            m = np.where(pick, m + 3.0 / (1.0 + np.exp(-(x1 - 1.0) / 0.3)), m)
+        rows = np.stack([x1, rng.normal(m, 0.5)], -1)
+    elif density == "gaussian_blobs":  # src/densities/gaussian_blobs.py:34-59
+        k = rng.integers(0, 8, n)
+        th = 2.0 * np.pi * k / 8.0
+        rows = np.stack([2.0 * np.cos(th), 2.0 * np.sin(th)], -1) + rng.normal(0.0, 0.3, (n, 2))
+    elif density == "mnist_like":  # src/maf_mnist.py:101-106 eval path: k/256
+        rows = rng.integers(0, 256, (n, 784)).astype(np.float64) / 256.0
+    else:
+        raise ValueError(density)
+    return rows.astype(np.float32)

@@ -1,0 +1,289 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance (stated once, used everywhere for float32 log_prob / log-det values):
+
+    |hip - oracle_f64| <= 1e-5 * max(1, |oracle_f64|)
+
+i.e. 1e-5 absolute for O(1) values and 1e-5 relative beyond.  One float32 ulp of
+a log_prob of magnitude 32 is already 3.8e-6 and the NumPy float32 restatement
+itself differs from float64 by up to ~1.8e-5 at |log_prob| <= 20
+(DESIGN.md "Tolerance"), so an unconditional absolute 1e-5 is below what the
+reference's own arithmetic type resolves.
+"""
+import numpy as np
+import pytest
+
+from oracle import flows_np as O
+
+pytestmark = pytest.mark.gpu
+
+DENSITIES = ["banana", "energy1", "energy2", "energy3", "energy4", "gaussian_blobs"]
+
+
+def tol(ref):
+    return 1e-5 * np.maximum(1.0, np.abs(ref))
+
+
+def assert_close(got, ref, what):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    bad = ~(np.abs(got - ref) <= tol(ref))
+    bad &= ~((got == ref))  # equal infinities
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.size} outside tolerance, worst abs "
+                           f"{np.nanmax(np.abs(got - ref))} at ref {ref.ravel()[np.nanargmax(np.abs(got - ref))]}")
+
+
+@pytest.fixture(scope="module")
+def nfa(nf_lib):
+    from normalizing_flows_amd import _lib, flow
+    _lib.require_device()
+    return flow
+
+
+def affine_flow(nfa, spec, parity=1):
+    from normalizing_flows_amd import _lib
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=spec.event_size,
+                         num_layers=len(spec.layers),
+                         hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]),
+                         first_mask_parity=parity)
+    return nfa.CouplingFlow(cfg, spec.layers)
+
+
+def split_flow(nfa, params, first_flip=0):
+    from normalizing_flows_amd import _lib
+    layers = [[(W, b) for W, b in net] for net in params]
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=len(params),
+                         hidden=tuple(W.shape[1] for W, _ in params[0][:-1]),
+                         activation=_lib.ACT_LEAKY_RELU, first_mask_parity=first_flip)
+    return nfa.CouplingFlow(cfg, layers)
+
+
+# ------------------------------------------------------------------ variant B
+@pytest.mark.parametrize("density", DENSITIES)
+def test_affine_log_prob_l8(nfa, density):
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    assert f.kernel_name == "affine2d_h64_mfma"
+    x = O.make_inputs(density, 4096)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"log_prob {density}")
+
+
+def test_affine_config1_l4_banana(nfa):
+    """BASELINE.json configs[0]: 4 layers, banana, batch 4096."""
+    spec = O.make_affine_spec(4, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("banana", 4096)
+    ref = O.log_prob(spec, x)
+    got = f.log_prob(x)
+    assert_close(got, ref, "config1")
+    # no worse than twice the float32 restatement's own distance from float64
+    e32 = np.abs(O.log_prob(spec, x, np.float32).astype(np.float64) - ref).max()
+    assert np.abs(got - ref).max() <= max(2 * e32, 1e-5)
+    assert abs(f.nll(x) - O.nll(spec, x)) <= 1e-5
+
+
+@pytest.mark.parametrize("L,parity", [(1, 1), (1, 0), (2, 1), (3, 0), (5, 1), (9, 1), (10, 1), (12, 0), (19, 1)])
+def test_affine_layer_counts_and_parity(nfa, L, parity):
+    spec = O.make_affine_spec(L, final_std=0.02, first_parity=parity)
+    f = affine_flow(nfa, spec, parity)
+    x = O.make_inputs("energy2", 1500)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"L={L} parity={parity}")
+
+
+@pytest.mark.parametrize("rows", [1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 4097, 70001, 300000])
+def test_affine_ragged_rows(nfa, rows):
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("gaussian_blobs", rows, seed=rows)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"rows={rows}")
+
+
+def test_affine_identity_at_init(nfa):
+    """Zero final Linear (src/real_nvp_toy_densities.py:64-68): flow == identity."""
+    spec = O.make_affine_spec(8, final_std=0.0)
+    f = affine_flow(nfa, spec)
+    from normalizing_flows_amd import _lib
+    x = O.make_inputs("banana", 2048)
+    lp = f.log_prob(x)
+    base = (-0.5 * (x.astype(np.float64) ** 2).sum(-1) - np.log(2 * np.pi))
+    assert_close(lp, base, "identity log_prob")
+    y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    assert np.array_equal(y, x)
+    assert np.all(ld == 0)
+
+
+def test_affine_chain_directions(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("energy4", 3000)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    assert_close(z, zr, "chain forward y")
+    assert_close(ld, ldr, "chain forward logdet")
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr2 = O.chain_inverse(spec, z)
+    assert_close(xb, xr, "chain inverse x")
+    assert_close(ldb, ldr2, "chain inverse logdet")
+    # round trip through the device both ways
+    assert np.abs(xb - x).max() <= 2e-5 * max(1, np.abs(x).max())
+    assert np.abs(ld + ldb).max() <= 1e-5
+
+
+def test_affine_single_layers_and_subchains(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(6, final_std=0.03)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("banana", 1111)
+    for l in range(6):
+        y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, l, l + 1)
+        yr, ldr = O.coupling_layer(spec, l, x, False)
+        assert_close(y, yr, f"layer {l} fwd y")
+        assert_close(ld, ldr, f"layer {l} fwd logdet")
+        y, ld = f.chain_apply(_lib.DIR_CHAIN_INVERSE, x, l, l + 1)
+        yr, ldr = O.coupling_layer(spec, l, x, True)
+        assert_close(y, yr, f"layer {l} inv y")
+        assert_close(ld, ldr, f"layer {l} inv logdet")
+    # layers [2,5): forward walks 4,3,2
+    y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, 2, 5)
+    v, tot = x.astype(np.float64), 0.0
+    for l in (4, 3, 2):
+        v, d = O.coupling_layer(spec, l, v, False)
+        tot = tot + d
+    assert_close(y, v, "subchain y")
+    assert_close(ld, tot, "subchain logdet")
+
+
+def test_affine_chain_order_matters(nfa):
+    """KAT 6: swapping two distinguishable layers changes the result."""
+    spec = O.make_affine_spec(2, final_std=0.05)
+    swapped = O.FlowSpec("affine", 2, spec.layers[::-1], spec.masks)
+    x = O.make_inputs("energy1", 512)
+    a = affine_flow(nfa, spec).log_prob(x)
+    b = affine_flow(nfa, swapped).log_prob(x)
+    assert np.abs(a - b).max() > 1e-3
+    assert_close(b, O.log_prob(swapped, x), "swapped layers")
+
+
+def test_affine_nll_and_device_resident(nfa):
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("energy3", 1 << 16)
+    ref = O.log_prob(spec, x)
+    xd = nfa.DeviceArray.from_numpy(x)
+    lpd = f.log_prob(xd)
+    f.synchronize()
+    assert_close(lpd.to_numpy(), ref, "device-resident log_prob")
+    assert abs(f.nll(xd) - (-ref.mean())) <= 1e-5
+    assert abs(f.nll(x) - (-ref.mean())) <= 1e-5
+    # enqueue form, several slots in flight, per-sample output too
+    out = nfa.DeviceArray((x.shape[0],))
+    for slot in range(4):
+        f.nll_enqueue(xd, x.shape[0], slot, out if slot == 3 else None)
+    f.synchronize()
+    vals = [f.nll_result(s) for s in range(4)]
+    assert max(vals) == min(vals), "fixed-order float64 reduction must be run-to-run identical"
+    assert_close(out.to_numpy(), ref, "enqueue log_prob")
+    # sharded: two halves with rows_global = all rows sum to the whole
+    half = x.shape[0] // 2
+    a = f.nll(xd.rows(0, half), rows_global=x.shape[0])
+    b = f.nll(xd.rows(half, x.shape[0]), rows_global=x.shape[0])
+    assert abs((a + b) - (-ref.mean())) <= 1e-6
+
+
+def test_affine_full_size_properties(nfa):
+    """BASELINE size (2^20 rows): size-independent properties instead of the oracle."""
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    n = 1 << 20
+    x = O.make_inputs("banana", n)
+    lp = f.log_prob(x)
+    assert np.isfinite(lp).all()
+    # (a) a 4096-row slice evaluated alone gives the same bits (no cross-sample coupling)
+    for s in (0, 4096 * 17, n - 4096):
+        assert np.array_equal(f.log_prob(x[s:s + 4096]), lp[s:s + 4096])
+    # (b) log_prob == base(z) + logdet with z, logdet from the chain walk
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    recon = -0.5 * (z.astype(np.float64) ** 2).sum(-1) - np.log(2 * np.pi) + ld
+    assert_close(lp, recon, "log_prob = base + logdet")
+    # (c) inverse(forward(x)) == x and the log-dets cancel
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    assert np.abs(xb - x).max() <= 1e-4 * max(1.0, np.abs(x).max())
+    assert np.abs(ld + ldb).max() <= 1e-4
+    # (d) NLL equals the float64 mean of the per-sample values
+    assert abs(f.nll(x) + lp.astype(np.float64).mean()) <= 1e-9
+    # (e) an oracle spot check on a strided sample of the big batch
+    idx = np.arange(0, n, 257)
+    assert_close(lp[idx], O.log_prob(spec, x[idx]), "strided oracle check")
+
+
+def test_errors(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(2)
+    f = affine_flow(nfa, spec)
+    with pytest.raises(ValueError):
+        f.log_prob(np.zeros((4, 3), np.float32))
+    with pytest.raises(_lib.NFError):
+        f.chain_apply(_lib.DIR_CHAIN_FORWARD, np.zeros((4, 2), np.float32), 1, 5)
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=2, hidden=(64, 64))
+    g = nfa.CouplingFlow(cfg)
+    with pytest.raises(_lib.NFError):
+        g.log_prob(np.zeros((4, 2), np.float32))  # weights never set
+    assert f.log_prob(np.zeros((0, 2), np.float32)).shape == (0,)
+
+
+# ------------------------------------------------------------------ variant A
+@pytest.mark.parametrize("density", DENSITIES)
+def test_split_log_prob(nfa, density):
+    params, flips = O.make_a_params(8)
+    f = split_flow(nfa, params)
+    assert f.kernel_name == "split2d_small"
+    x = O.make_inputs(density, 4097)
+    assert_close(f.log_prob(x), O.a_log_prob_chain(params, flips, x), f"A log_prob {density}")
+
+
+@pytest.mark.parametrize("L,H,rows", [(1, 4, 1), (2, 4, 2), (3, 7, 255), (8, 16, 513), (11, 4, 10000)])
+def test_split_shapes(nfa, L, H, rows):
+    params, flips = O.make_a_params(L, sizes=(1, H, 2))
+    for net in params:  # non-zero biases so they are exercised
+        for j, (W, b) in enumerate(net):
+            net[j][1] = (np.arange(b.size) * 0.01 - 0.02).astype(np.float32)
+    f = split_flow(nfa, params)
+    x = O.make_inputs("energy2", rows, seed=rows)
+    assert_close(f.log_prob(x), O.a_log_prob_chain(params, flips, x), "A shapes")
+
+
+def test_split_sampling_direction_and_layers(nfa):
+    from normalizing_flows_amd import _lib
+    params, flips = O.make_a_params(8)
+    f = split_flow(nfa, params)
+    z = np.random.default_rng(7809).standard_normal((5000, 2)).astype(np.float32)
+    y, _ = f.chain_apply(_lib.DIR_FIRST_TO_LAST_FORWARD, z)
+    assert_close(y, O.a_sample_chain_from_z(params, flips, z), "A sample chain")
+    back, ld = f.chain_apply(_lib.DIR_LAST_TO_FIRST_INVERSE, y)
+    assert np.abs(back - z).max() <= 2e-5
+    for l in range(8):
+        x1, ls = O.a_inverse_layer(params[l], y, flips[l])
+        got, gld = f.chain_apply(_lib.DIR_LAST_TO_FIRST_INVERSE, y, l, l + 1)
+        assert_close(got, x1, f"A inverse layer {l}")
+        assert_close(gld, -ls.sum(-1), f"A inverse layer {l} logdet")
+        got, _ = f.chain_apply(_lib.DIR_FIRST_TO_LAST_FORWARD, y, l, l + 1)
+        assert_close(got, O.a_forward_layer(params[l], y, flips[l]), f"A forward layer {l}")
+    assert abs(f.nll(y) - O.a_nll(params, flips, y)) <= 1e-5
+
+
+# ------------------------------------------------------------------ RCCL (1 rank on the 1-GPU box)
+def test_rccl_single_rank_allreduce(nfa):
+    from normalizing_flows_amd import sharding
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    x = O.make_inputs("banana", 8192)
+    plain = f.nll(x)
+    comm = sharding.RcclComm(1, 0, sharding.RcclComm.new_unique_id())
+    f.attach_comm(comm)
+    with_comm = f.nll(x)
+    f.attach_comm(None)
+    comm.close()
+    assert with_comm == plain
