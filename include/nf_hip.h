@@ -148,6 +148,17 @@ int nf_flow_synchronize(nf_flow* flow);
    (src/real_nvp.py:57-68,268-283).  out_log_prob[rows]. */
 int nf_log_prob(nf_flow* flow, const float* x, int64_t rows, float* out_log_prob, int mem);
 
+/* Same with the chain walked in an explicit nf_direction before the base
+   log-density is added: Transformed(base, bijector).log_prob for a bijector that
+   is the chain itself rather than Inverse(chain). */
+int nf_chain_log_prob(nf_flow* flow, int direction, const float* x, int64_t rows,
+                      float* out_log_prob, int mem);
+
+/* Base log-density alone: Independent(Normal(0,1)).log_prob / log_prob_N01
+   (src/real_nvp.py:57-68, src/real_nvp_toy_densities.py:105-108) or
+   Independent(Uniform(0,1)).log_prob (src/maf_mnist.py:84-88).  No handle needed. */
+int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, float* out, int mem);
+
 /* Replaces Chain / MaskedCoupling forward_and_log_det, inverse_and_log_det and
    forward_nvp / inverse_nvp chains (see nf_direction).  Walks layers
    [layer_begin, layer_end) of the chain; pass 0, num_layers for the whole chain,

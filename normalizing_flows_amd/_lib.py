@@ -82,6 +82,8 @@ PROTOTYPES = {
     "nf_flow_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nf_flow_synchronize": (C.c_int, [C.c_void_p]),
     "nf_log_prob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "nf_chain_log_prob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "nf_base_log_prob": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_chain_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int]),
     "nf_nll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,

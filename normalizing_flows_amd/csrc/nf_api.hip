@@ -116,6 +116,7 @@ struct nf_flow {
   bool have_weights = false;
   size_t weight_count = 0;
   float* d_wimg = nullptr;  // path-specific packed weights
+  generic::Plan plan;       // PATH_GENERIC
   // staging for NF_MEM_HOST calls and for chains longer than one launch
   float *d_x = nullptr, *d_y = nullptr, *d_ld = nullptr, *d_lp = nullptr;
   long long stage_rows = 0;
@@ -187,9 +188,24 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
     }
     return NF_OK;
   }
-  set_error("flow configuration (kind %d, D=%d, %d hidden layers) has no kernel in this build yet",
-            f->desc.kind, f->desc.event_dim, f->desc.num_hidden);
-  return NF_ERR_UNSUPPORTED;
+  // general path: state lives in y / ld and is updated in place, layer by layer
+  const int D = f->desc.event_dim;
+  if (!io.y || !io.logdet_out) NF_TRY(ensure_stage(f, io.rows));
+  float* y = io.y ? io.y : f->d_y;
+  float* ld = io.logdet_out ? io.logdet_out : f->d_ld;
+  if (y != io.x)
+    NF_HIP(hipMemcpyAsync(y, io.x, sizeof(float) * io.rows * D, hipMemcpyDeviceToDevice, f->stream));
+  if (io.logdet_in) {
+    if (ld != io.logdet_in)
+      NF_HIP(hipMemcpyAsync(ld, io.logdet_in, sizeof(float) * io.rows, hipMemcpyDeviceToDevice, f->stream));
+  } else {
+    NF_HIP(hipMemsetAsync(ld, 0, sizeof(float) * io.rows, f->stream));
+  }
+  NF_TRY(f->plan.walk(y, ld, io, f->stream));
+  if (io.logprob_out || io.block_sums)
+    NF_TRY(generic::launch_base_log_prob(y, ld, io.logprob_out, io.block_sums, io.rows, D, io.base,
+                                         f->stream, out_grid));
+  return NF_OK;
 }
 
 static int check_ready(nf_flow* f, const void* x, long long rows) {
@@ -305,6 +321,7 @@ void nf_flow_destroy(nf_flow* f) {
   if (!f) return;
   if (f->stream) hipStreamSynchronize(f->stream);
   hipFree(f->d_wimg);
+  f->plan.release();
   hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp);
   hipFree(f->d_block_sums); hipFree(f->d_sum);
   if (f->h_ring) hipHostFree(f->h_ring);
@@ -343,9 +360,10 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
     // W0[1][H], b0[H], W1[H][2], b1[2] is already the kernel's order
     img.assign(packed, packed + count);
   } else {
-    set_error("flow configuration (kind %d, D=%d, %d hidden layers) has no kernel in this build yet",
-              d.kind, d.event_dim, d.num_hidden);
-    return NF_ERR_UNSUPPORTED;
+    NF_HIP(hipStreamSynchronize(f->stream));
+    NF_TRY(f->plan.build(d, packed));
+    f->have_weights = true;
+    return NF_OK;
   }
   NF_HIP(hipStreamSynchronize(f->stream));
   if (f->d_wimg) { hipFree(f->d_wimg); f->d_wimg = nullptr; }
@@ -401,15 +419,18 @@ int nf_chain_apply(nf_flow* f, int direction, int layer_begin, int layer_end, co
   return NF_OK;
 }
 
-static int enqueue_log_prob(nf_flow* f, const float* x_dev, long long rows, float* lp_dev,
+static int default_direction(const nf_flow* f) {
+  return f->desc.kind == NF_KIND_AFFINE_SPLIT ? NF_DIR_LAST_TO_FIRST_INVERSE : NF_DIR_CHAIN_FORWARD;
+}
+
+static int enqueue_log_prob(nf_flow* f, int direction, const float* x_dev, long long rows, float* lp_dev,
                             bool want_sum, int* out_grid) {
   ChainIO io;
   memset(&io, 0, sizeof(io));
   io.rows = rows;
   io.layer_begin = 0;
   io.layer_end = f->desc.num_layers;
-  direction_flags(f->desc.kind == NF_KIND_AFFINE_SPLIT ? NF_DIR_LAST_TO_FIRST_INVERSE : NF_DIR_CHAIN_FORWARD,
-                  &io.descending, &io.inverse_op);
+  direction_flags(direction, &io.descending, &io.inverse_op);
   io.x = x_dev;
   io.logprob_out = lp_dev;
   io.block_sums = want_sum ? f->d_block_sums : nullptr;
@@ -418,17 +439,25 @@ static int enqueue_log_prob(nf_flow* f, const float* x_dev, long long rows, floa
 }
 
 int nf_log_prob(nf_flow* f, const float* x, int64_t rows, float* out_log_prob, int mem) {
+  if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
+  return nf_chain_log_prob(f, default_direction(f), x, rows, out_log_prob, mem);
+}
+
+int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, float* out_log_prob, int mem) {
   NF_TRY(check_ready(f, x, rows));
+  if (direction < NF_DIR_CHAIN_FORWARD || direction > NF_DIR_LAST_TO_FIRST_INVERSE) {
+    set_error("unknown direction %d", direction); return NF_ERR_INVALID;
+  }
   if (!out_log_prob && rows > 0) { set_error("out_log_prob is NULL"); return NF_ERR_INVALID; }
   if (rows == 0) return NF_OK;
   if (mem == NF_MEM_DEVICE) {
     NF_TRY(check_device_ptr(x, "x")); NF_TRY(check_device_ptr(out_log_prob, "out_log_prob"));
-    return enqueue_log_prob(f, x, rows, out_log_prob, false, nullptr);
+    return enqueue_log_prob(f, direction, x, rows, out_log_prob, false, nullptr);
   }
   NF_TRY(ensure_stage(f, rows));
   const int D = f->desc.event_dim;
   NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
-  NF_TRY(enqueue_log_prob(f, f->d_x, rows, f->d_lp, false, nullptr));
+  NF_TRY(enqueue_log_prob(f, direction, f->d_x, rows, f->d_lp, false, nullptr));
   NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows, hipMemcpyDeviceToHost, f->stream));
   NF_HIP(hipStreamSynchronize(f->stream));
   return NF_OK;
@@ -442,7 +471,7 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   NF_TRY(check_device_ptr(x_dev, "x")); NF_TRY(check_device_ptr(out_log_prob_dev, "out_log_prob"));
   int grid = 0;
   if (rows_local > 0) {
-    NF_TRY(enqueue_log_prob(f, x_dev, rows_local, out_log_prob_dev, true, &grid));
+    NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, true, &grid));
     NF_TRY(launch_sum_blocks(f->d_block_sums, grid, f->d_sum + slot, f->stream));
   } else {
     NF_HIP(hipMemsetAsync(f->d_sum + slot, 0, sizeof(double), f->stream));
@@ -481,6 +510,30 @@ int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, 
     NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows_local, hipMemcpyDeviceToHost, f->stream));
   NF_HIP(hipStreamSynchronize(f->stream));
   return nf_nll_result(f, 0, out_nll);
+}
+
+int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, float* out, int mem) {
+  if (base != NF_BASE_STD_NORMAL && base != NF_BASE_UNIFORM01) { set_error("unknown base %d", base); return NF_ERR_INVALID; }
+  if (event_dim < 1 || rows < 0) { set_error("bad shape"); return NF_ERR_INVALID; }
+  if (rows == 0) return NF_OK;
+  if (!x || !out) { set_error("x or out is NULL"); return NF_ERR_INVALID; }
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(generic::launch_base_log_prob(x, nullptr, out, nullptr, rows, event_dim, base, nullptr, nullptr));
+    return NF_OK;
+  }
+  float *dx = nullptr, *dl = nullptr;
+  NF_HIP(hipMalloc(&dx, sizeof(float) * rows * event_dim));
+  hipError_t e = hipMalloc(&dl, sizeof(float) * rows);
+  if (e != hipSuccess) { hipFree(dx); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+  int s = NF_OK;
+  if ((e = hipMemcpy(dx, x, sizeof(float) * rows * event_dim, hipMemcpyHostToDevice)) != hipSuccess)
+    s = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+  if (s == NF_OK) s = generic::launch_base_log_prob(dx, nullptr, dl, nullptr, rows, event_dim, base, nullptr, nullptr);
+  if (s == NF_OK && (e = hipMemcpy(out, dl, sizeof(float) * rows, hipMemcpyDeviceToHost)) != hipSuccess)
+    s = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+  hipFree(dx);
+  hipFree(dl);
+  return s;
 }
 
 int nf_timer_start(nf_flow* f) {

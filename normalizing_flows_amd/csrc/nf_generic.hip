@@ -1,0 +1,477 @@
+// General path: any event size, any conditioner widths, all three coupling kinds.
+//
+// One coupling layer = a chain of f32-MFMA GEMMs (conditioner MLP, bias +
+// activation fused into the epilogue) followed by one transform kernel (affine or
+// rational-quadratic spline) that updates the sample matrix and the running
+// log-det in place.  Activations and conditioner outputs live in device scratch,
+// the batch is walked in row chunks so the scratch stays bounded.
+//
+// This is the path of the reference's spline flows (src/maf_toy_densities.py:55-111,
+// src/maf_mnist.py:34-89; distrax RationalQuadraticSpline semantics in SURVEY.md
+// section 8a row c2) and of every affine configuration the two fused kernels do
+// not cover.  Mask handling: the first Linear's rows of the transformed dims are
+// zeroed on the host (x @ W' == where(mask, x, 0) @ W) and only the spline
+// parameters of the transformed dims are computed (the others are never read by
+// distrax.MaskedCoupling either: y = where(mask, x, y0)).
+#include "nf_internal.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+namespace nf {
+namespace generic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------
+// C[M,N] = act(A[M,K] @ W[K,N] + bias[N]);  A row-major with leading dim lda,
+// W row-major [K,N], C row-major with leading dim ldc.
+// MFMA 32x32x2 f32: rows = samples, cols = output units.
+// ------------------------------------------------------------------------
+constexpr int BK = 16;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int act) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_PER = BM * BK / NT;  // floats of the A tile per thread
+  constexpr int W_PER = BK * BN / NT;
+  __shared__ float As[BM][BK + 1];
+  __shared__ float Ws[BK][BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float ra[A_PER], rw[W_PER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < A_PER; ++e) {
+      const int idx = tid + e * NT;  // over BM*BK, k fastest
+      const int r = idx / BK, k = idx % BK;
+      const int gr = m0 + r, gk = k0 + k;
+      ra[e] = (gr < M && gk < K) ? A[(size_t)gr * lda + gk] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < W_PER; ++e) {
+      const int idx = tid + e * NT;  // over BK*BN, n fastest
+      const int k = idx / BN, c = idx % BN;
+      const int gk = k0 + k, gc = n0 + c;
+      rw[e] = (gk < K && gc < N) ? W[(size_t)gk * N + gc] : 0.f;
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < A_PER; ++e) {
+      const int idx = tid + e * NT;
+      As[idx / BK][idx % BK] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < W_PER; ++e) {
+      const int idx = tid + e * NT;
+      Ws[idx / BN][idx % BN] = rw[e];
+    }
+    __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = As[wm * (TM * 32) + t * 32 + i][2 * s + h];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = Ws[2 * s + h][wn * (TN * 32) + t * 32 + i];
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      const int col = n0 + wn * (TN * 32) + u * 32 + i;
+      if (col >= N) continue;
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (TM * 32) + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (row >= M) continue;
+        float v = acc[t][u][r] + bv;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+        Cm[(size_t)row * ldc + col] = v;
+      }
+    }
+}
+
+static int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
+                       int M, int N, int K, int act, hipStream_t stream) {
+  if (N > 64) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_bias_act_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, A, lda, W,
+                       bias, Cm, ldc, M, N, K, act);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_bias_act_kernel<128, 64, 4, 1>), grid, dim3(256), 0, stream, A, lda, W,
+                       bias, Cm, ldc, M, N, K, act);
+  }
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+// ------------------------------------------------------------------------
+// transforms
+// ------------------------------------------------------------------------
+// masked affine: params[rows][2] = (shift, log_scale), broadcast over the event;
+// dims with (d % 2 == pass_parity) pass through.
+__global__ __launch_bounds__(256) void affine_masked_kernel(float* __restrict__ y, float* __restrict__ ld,
+                                                           const float* __restrict__ params, long long rows,
+                                                           int D, int pass_parity, int inverse) {
+  const long long total = rows * (long long)D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / D;
+    const int d = (int)(e % D);
+    const float shift = params[2 * row], ls = params[2 * row + 1];
+    if ((d & 1) != pass_parity) {
+      const float v = y[e];
+      y[e] = inverse ? (v - shift) * expf(-ls) : fmaf(v, expf(ls), shift);
+    }
+    if (d == 0) {
+      const int n_t = pass_parity == 0 ? D / 2 : (D + 1) / 2;  // transformed dims: d % 2 != pass_parity
+      const float add = (float)n_t * ls;
+      ld[row] += inverse ? -add : add;
+    }
+  }
+}
+
+// split halves (variant A, any even D): params[rows][D] = (shift[d] | log_scale[d]);
+// flip = 0 transforms the second half conditioned on the first.
+__global__ __launch_bounds__(256) void affine_split_kernel(float* __restrict__ y, float* __restrict__ ld,
+                                                          const float* __restrict__ params, long long rows,
+                                                          int D, int flip, int inverse) {
+  const int d = D / 2;
+  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long long)gridDim.x * 256) {
+    float* v = y + row * D + (flip ? 0 : d);
+    const float* p = params + row * D;
+    float acc = 0.f;
+    for (int c = 0; c < d; ++c) {
+      const float shift = p[c], ls = p[d + c];
+      v[c] = inverse ? (v[c] - shift) * expf(-ls) : fmaf(v[c], expf(ls), shift);
+      acc += ls;
+    }
+    ld[row] += inverse ? -acc : acc;
+  }
+}
+
+struct RqsConst {
+  int K;
+  float range_min, range_max, min_bin, min_slope, slope_offset;
+};
+
+__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
+
+// One (row, transformed dim): spline forward or inverse, returns the new value and log|det|.
+// p points at the 3K+1 raw parameters [widths K | heights K | slopes K+1].
+__device__ __forceinline__ void rqs_eval(const float* __restrict__ p, const RqsConst& c, float v, int inverse,
+                                         float* out, float* logdet) {
+  const int K = c.K;
+  const float total = c.range_max - c.range_min;
+  const float scale = total - (float)K * c.min_bin;
+  float mw = -INFINITY, mh = -INFINITY;
+  for (int k = 0; k < K; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
+  float sw = 0.f, sh = 0.f;
+  for (int k = 0; k < K; ++k) { sw += expf(p[k] - mw); sh += expf(p[K + k] - mh); }
+  const float iw = scale / sw, ih = scale / sh;
+  const float s_first = softplus_f(p[2 * K] + c.slope_offset) + c.min_slope;
+  const float s_last = softplus_f(p[3 * K] + c.slope_offset) + c.min_slope;
+  // walk the bins once, keeping the one that contains v (bin 0 when none does)
+  float xl = c.range_min, yl = c.range_min, sl = s_first;
+  float bxl = 0.f, bxr = 0.f, byl = 0.f, byr = 0.f, bsl = 0.f, bsr = 0.f;
+  bool found = false;
+  for (int k = 0; k < K; ++k) {
+    const float w = expf(p[k] - mw) * iw + c.min_bin;
+    const float hgt = expf(p[K + k] - mh) * ih + c.min_bin;
+    const float xr = k == K - 1 ? c.range_max : xl + w;
+    const float yr = k == K - 1 ? c.range_max : yl + hgt;
+    const float sr = k == K - 1 ? s_last : softplus_f(p[2 * K + k + 1] + c.slope_offset) + c.min_slope;
+    const float lo = inverse ? yl : xl, hi = inverse ? yr : xr;
+    const bool hit = (v >= lo) && (v < hi);
+    if ((hit && !found) || k == 0) { bxl = xl; bxr = xr; byl = yl; byr = yr; bsl = sl; bsr = sr; }
+    found = found || hit;
+    xl = xr; yl = yr; sl = sr;
+  }
+  const float bw = bxr - bxl, bh = byr - byl;
+  const float delta = bh / bw;
+  const float st = bsr + bsl - 2.f * delta;
+  float res, ldv;
+  if (!inverse) {
+    float z = (v - bxl) / bw;
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float num = bh * (delta * zz + bsl * z1mz);
+    const float den = delta + st * z1mz;
+    res = byl + num / den;
+    ldv = 2.f * logf(delta) + logf(bsr * zz + 2.f * delta * z1mz + bsl * omz * omz) - 2.f * logf(den);
+    if (v <= c.range_min) { res = (v - c.range_min) * s_first + c.range_min; ldv = logf(s_first); }
+    if (v >= c.range_max) { res = (v - c.range_max) * s_last + c.range_max; ldv = logf(s_last); }
+  } else {
+    float u = (v - byl) / bh;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    const float qc = -delta * u;
+    const float qb = bsl - st * u;
+    const float qa = delta - qb;
+    float z = -2.f * qc / (qb + sqrtf(qb * qb - 4.f * qa * qc));
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    res = bw * z + bxl;
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float den = delta + st * z1mz;
+    ldv = -2.f * logf(delta) - logf(bsr * zz + 2.f * delta * z1mz + bsl * omz * omz) + 2.f * logf(den);
+    if (v <= c.range_min) { res = (v - c.range_min) / s_first + c.range_min; ldv = -logf(s_first); }
+    if (v >= c.range_max) { res = (v - c.range_max) / s_last + c.range_max; ldv = -logf(s_last); }
+  }
+  *out = res;
+  *logdet = ldv;
+}
+
+// G lanes (power of two <= 64) share one row: each takes transformed dims dt = sub, sub+G, ...
+// params[rows][Dt][3K+1] holds ONLY the transformed dims' parameters.
+__global__ __launch_bounds__(256) void rqs_masked_kernel(float* __restrict__ y, float* __restrict__ ld,
+                                                        const float* __restrict__ params, long long rows,
+                                                        int D, int pass_parity, int inverse, int G, RqsConst c) {
+  const int P = 3 * c.K + 1;
+  const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
+  const int first_t = pass_parity == 0 ? 1 : 0;  // first transformed dim
+  const long long lanes = rows * (long long)G;
+  const long long span = ((lanes + 255) / 256) * 256;  // keep whole groups in lock step for the shuffles
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < span; e += (long long)gridDim.x * 256) {
+    const long long row = e / G;
+    const int sub = (int)(e % G);
+    float acc = 0.f;
+    if (row < rows) {
+      for (int dt = sub; dt < Dt; dt += G) {
+        const int d = first_t + 2 * dt;
+        float res, l;
+        rqs_eval(params + ((size_t)row * Dt + dt) * P, c, y[row * D + d], inverse, &res, &l);
+        y[row * D + d] = res;
+        acc += l;
+      }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (row < rows && sub == 0) ld[row] += acc;
+  }
+}
+
+// log_prob = base log-density(z) + logdet; optional float64 block sums.
+__global__ __launch_bounds__(256) void base_log_prob_kernel(const float* __restrict__ z, const float* __restrict__ ld,
+                                                           float* __restrict__ lp, double* __restrict__ block_sums,
+                                                           long long rows, int D, int base) {
+  double sum = 0.0;
+  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long long)gridDim.x * 256) {
+    const float* v = z + row * D;
+    float out;
+    if (base == NF_BASE_STD_NORMAL) {
+      float ss = 0.f;
+      for (int d = 0; d < D; ++d) ss = fmaf(v[d], v[d], ss);
+      out = -0.5f * ss - (float)D * 0.9189385332046727f;
+    } else {
+      bool inside = true;
+      for (int d = 0; d < D; ++d) inside = inside && v[d] >= 0.f && v[d] <= 1.f;
+      out = inside ? 0.f : -INFINITY;
+    }
+    if (ld) out += ld[row];
+    if (lp) lp[row] = out;
+    sum += (double)out;
+  }
+  if (block_sums) {
+    __shared__ double red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,
+                         int D, int base, hipStream_t stream, int* out_grid) {
+  long long want = (rows + 255) / 256;
+  const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  if (out_grid) *out_grid = grid;
+  hipLaunchKernelGGL(base_log_prob_kernel, dim3(grid), dim3(256), 0, stream, z, ld, lp, block_sums, rows, D, base);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+// ------------------------------------------------------------------------
+// host side: weights and the layer walk
+// ------------------------------------------------------------------------
+int Plan::build(const nf_flow_desc& d, const float* packed) {
+  release();
+  desc = d;
+  std::vector<int> in, out;
+  const int nlin = d.num_hidden + 1;
+  int first_in, last_out;
+  const int P = 3 * d.rqs_bins + 1;
+  if (d.kind == NF_KIND_AFFINE_SPLIT) { first_in = d.event_dim / 2; last_out = d.event_dim; }
+  else if (d.kind == NF_KIND_AFFINE_MASKED) { first_in = d.event_dim; last_out = 2; }
+  else { first_in = d.event_dim; last_out = d.event_dim * P; }
+  int cur = first_in;
+  for (int j = 0; j < d.num_hidden; ++j) { in.push_back(cur); out.push_back(d.hidden[j]); cur = d.hidden[j]; }
+  in.push_back(cur); out.push_back(last_out);
+  size_t per_layer = 0;
+  for (int j = 0; j < nlin; ++j) per_layer += (size_t)in[j] * out[j] + out[j];
+
+  max_width = 0;
+  std::vector<float> host;
+  linears.assign((size_t)d.num_layers * nlin, Linear());
+  for (int l = 0; l < d.num_layers; ++l) {
+    const float* src = packed + per_layer * l;
+    const int pass_parity = (d.first_mask_parity + l) & 1;  // masked kinds
+    for (int j = 0; j < nlin; ++j) {
+      const float* W = src;
+      const float* b = src + (size_t)in[j] * out[j];
+      src = b + out[j];
+      Linear& L = linears[(size_t)l * nlin + j];
+      L.K = in[j];
+      L.N = out[j];
+      std::vector<float> w(W, W + (size_t)in[j] * out[j]);
+      std::vector<float> bb(b, b + out[j]);
+      if (d.kind != NF_KIND_AFFINE_SPLIT && j == 0) {
+        // where(mask, x, 0) @ W  ==  x @ W with the transformed dims' rows zeroed
+        for (int r = 0; r < in[j]; ++r)
+          if ((r & 1) != pass_parity)
+            for (int c = 0; c < out[j]; ++c) w[(size_t)r * out[j] + c] = 0.f;
+      }
+      if (d.kind == NF_KIND_RQS_MASKED && j == nlin - 1) {
+        // keep the parameter columns of the transformed dims only
+        const int D = d.event_dim;
+        std::vector<int> tdims;
+        for (int e = 0; e < D; ++e) if ((e & 1) != pass_parity) tdims.push_back(e);
+        const int Nn = (int)tdims.size() * P;
+        std::vector<float> w2((size_t)in[j] * Nn), b2(Nn);
+        for (size_t t = 0; t < tdims.size(); ++t)
+          for (int q = 0; q < P; ++q) {
+            const int cs = tdims[t] * P + q, cd = (int)t * P + q;
+            b2[cd] = bb[cs];
+            for (int r = 0; r < in[j]; ++r) w2[(size_t)r * Nn + cd] = w[(size_t)r * out[j] + cs];
+          }
+        w.swap(w2);
+        bb.swap(b2);
+        L.N = Nn;
+      }
+      max_width = std::max(max_width, L.N);
+      L.w_off = host.size();
+      host.insert(host.end(), w.begin(), w.end());
+      while (host.size() % 4) host.push_back(0.f);
+      L.b_off = host.size();
+      host.insert(host.end(), bb.begin(), bb.end());
+      while (host.size() % 4) host.push_back(0.f);
+    }
+  }
+  NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
+  NF_HIP(hipMemcpy(d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return NF_OK;
+}
+
+void Plan::release() {
+  if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
+  if (d_scratch) { hipFree(d_scratch); d_scratch = nullptr; }
+  scratch_rows = 0;
+  linears.clear();
+}
+
+int Plan::ensure_scratch(long long rows) {
+  // three buffers of max_width floats per row (two activation ping-pongs + parameters)
+  const size_t per_row = (size_t)3 * max_width * sizeof(float);
+  long long cap = (long long)((size_t)768 * 1024 * 1024 / per_row);
+  cap = std::max<long long>(128, cap / 128 * 128);
+  const long long want = std::min(rows, cap);
+  if (want <= scratch_rows) return NF_OK;
+  if (d_scratch) { hipFree(d_scratch); d_scratch = nullptr; scratch_rows = 0; }
+  NF_HIP(hipMalloc(&d_scratch, per_row * (size_t)want));
+  scratch_rows = want;
+  return NF_OK;
+}
+
+// y (in place) and ld (in place) already hold the chain's input state.
+int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
+  const nf_flow_desc& d = desc;
+  const int D = d.event_dim;
+  const int nlin = d.num_hidden + 1;
+  const int nlay = io.layer_end - io.layer_begin;
+  NF_TRY(ensure_scratch(io.rows));
+  const int act = d.activation == NF_ACT_RELU ? 1 : 2;
+  RqsConst rc;
+  rc.K = d.rqs_bins;
+  rc.range_min = d.rqs_range_min;
+  rc.range_max = d.rqs_range_max;
+  rc.min_bin = d.rqs_min_bin_size;
+  rc.min_slope = d.rqs_min_knot_slope;
+  rc.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
+  for (long long r0 = 0; r0 < io.rows; r0 += scratch_rows) {
+    const long long n = std::min(scratch_rows, io.rows - r0);
+    float* yc = y + r0 * D;
+    float* ldc = ld + r0;
+    float* buf[3] = {d_scratch, d_scratch + (size_t)scratch_rows * max_width,
+                     d_scratch + (size_t)2 * scratch_rows * max_width};
+    for (int li = 0; li < nlay; ++li) {
+      const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
+      const int par = (d.first_mask_parity + l) & 1;  // masked: pass-through parity; split: flip
+      const float* a = yc;
+      int lda = D;
+      if (d.kind == NF_KIND_AFFINE_SPLIT && par) a = yc + D / 2;  // flipped: second half conditions
+      for (int j = 0; j < nlin; ++j) {
+        const Linear& L = linears[(size_t)l * nlin + j];
+        float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
+        NF_TRY(launch_gemm(a, lda, d_weights + L.w_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
+                           j == nlin - 1 ? 0 : act, stream));
+        a = dst;
+        lda = L.N;
+      }
+      const float* params = buf[2];
+      if (d.kind == NF_KIND_AFFINE_MASKED) {
+        const long long total = n * D;
+        const int grid = (int)std::min<long long>(4096, (total + 255) / 256);
+        hipLaunchKernelGGL(affine_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
+                           io.inverse_op);
+      } else if (d.kind == NF_KIND_AFFINE_SPLIT) {
+        const int grid = (int)std::min<long long>(4096, (n + 255) / 256);
+        hipLaunchKernelGGL(affine_split_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
+                           io.inverse_op);
+      } else {
+        const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+        int G = 1;
+        while (G < 64 && G < Dt) G <<= 1;
+        const long long lanes = n * G;
+        const int grid = (int)std::min<long long>(8192, (lanes + 255) / 256);
+        hipLaunchKernelGGL(rqs_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
+                           io.inverse_op, G, rc);
+      }
+      NF_HIP(hipGetLastError());
+    }
+  }
+  return NF_OK;
+}
+
+}  // namespace generic
+}  // namespace nf

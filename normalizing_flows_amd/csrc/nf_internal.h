@@ -79,6 +79,29 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
 int max_grid();
 }  // namespace split2d
 
+// ---- path 3: general path (GEMM chain + transform kernels), any D / widths / kind ---
+namespace generic {
+struct Linear {
+  int K = 0, N = 0;           // y[., N] = x[., K] @ W + b (after host-side pruning)
+  size_t w_off = 0, b_off = 0;  // offsets into d_weights, floats
+};
+struct Plan {
+  nf_flow_desc desc;
+  std::vector<Linear> linears;  // [layer][linear]
+  float* d_weights = nullptr;
+  float* d_scratch = nullptr;
+  long long scratch_rows = 0;
+  int max_width = 0;
+  int build(const nf_flow_desc& d, const float* packed);
+  void release();
+  int ensure_scratch(long long rows);
+  // y [rows, D] and ld [rows] hold the chain's input state and are updated in place
+  int walk(float* y, float* ld, const ChainIO& io, hipStream_t stream);
+};
+int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,
+                         int D, int base, hipStream_t stream, int* out_grid);
+}  // namespace generic
+
 // ---- float64 fixed-order reduction of per-block sums --------------------------
 int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream);
 
