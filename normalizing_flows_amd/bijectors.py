@@ -311,8 +311,7 @@ class Chain(Bijector):
                          is_constant_jacobian=all(b.is_constant_jacobian for b in bijectors),
                          is_constant_log_det=all(b.is_constant_log_det for b in bijectors))
         self._bijectors = list(bijectors)
-        self._flow: Optional[CouplingFlow] = None
-        self._flow_key = None
+        self._flows = {}  # base code -> (parameter key, CouplingFlow)
 
     bijectors = property(lambda self: self._bijectors)
 
@@ -333,23 +332,25 @@ class Chain(Bijector):
             if s.parity != (first.parity + l) % 2:
                 raise NotImplementedError("masks must alternate from layer to layer "
                                           "(mask = logical_not(mask), as in the reference)")
-        key = (base,) + tuple((id(b.conditioner), b.conditioner.version) for b in layers)
-        if self._flow is None or key != self._flow_key:
+        key = tuple((id(b.conditioner), b.conditioner.version) for b in layers)
+        cached = self._flows.get(base)
+        if cached is None or cached[0] != key:
             rqs = first.rqs or (0, 0.0, 1.0, 1e-4, 1e-4)
             cfg = FlowConfig(kind=first.kind, event_dim=int(np.prod(first.event_shape)),
                              num_layers=len(layers), hidden=first.hidden, activation=first.activation,
                              first_mask_parity=first.parity, base=base, rqs_bins=rqs[0],
                              rqs_range_min=rqs[1], rqs_range_max=rqs[2], rqs_min_bin_size=rqs[3],
                              rqs_min_knot_slope=rqs[4])
-            if self._flow is not None:
-                self._flow.close()
-            self._flow = CouplingFlow(cfg, [b.packed_linears() for b in layers])
-            self._flow_key = key
-        return self._flow, first.event_shape
+            if cached is not None:
+                cached[1].close()
+            cached = (key, CouplingFlow(cfg, [b.packed_linears() for b in layers]))
+            self._flows[base] = cached
+        return cached[1], first.event_shape
 
     def _walk(self, direction: int, v):
-        flow, event_shape = self.lowered(self._flow.config.base if self._flow is not None
-                                         else _lib.BASE_STD_NORMAL)
+        # the base density plays no part in a chain walk: reuse whichever handle exists
+        base = next(iter(self._flows), _lib.BASE_STD_NORMAL)
+        flow, event_shape = self.lowered(base)
         rows, batch = _flatten_rows(v, event_shape)
         y, ld = flow.chain_apply(direction, rows)
         return _unflatten(y, ld, batch, event_shape)

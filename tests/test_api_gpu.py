@@ -1,0 +1,224 @@
+"""The reference's scripts, re-typed against this package (imports swapped, nothing else),
+checked against the oracle.  Each helper below mirrors the named reference function."""
+import numpy as np
+import pytest
+
+from oracle import flows_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def tol(ref):
+    return 1e-5 * np.maximum(1.0, np.abs(ref))
+
+
+@pytest.fixture(scope="module")
+def distrax(nf_lib):
+    import normalizing_flows_amd as pkg
+    from normalizing_flows_amd import _lib
+    _lib.require_device()
+    return pkg
+
+
+def make_flow_model_affine(distrax, event_shape, num_layers, hidden_sizes, rng, final_std):
+    """src/real_nvp_toy_densities.py:74-110 with `jnp` -> `np` and haiku -> make_conditioner."""
+    mask = np.arange(0, np.prod(event_shape)) % 2
+    mask = np.reshape(mask, event_shape).astype(bool)
+
+    def bijector_fn(params):
+        shift, log_scale = np.split(params, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+
+    layers = []
+    for _ in range(num_layers):
+        layers.append(distrax.MaskedCoupling(
+            mask=mask, bijector=bijector_fn,
+            conditioner=distrax.make_conditioner(event_shape, hidden_sizes, 2, rng=rng, final_std=final_std)))
+        mask = np.logical_not(mask)
+    flow = distrax.Inverse(distrax.Chain(layers))
+    base = distrax.Independent(distrax.Normal(loc=np.zeros(event_shape), scale=np.ones(event_shape)),
+                               reinterpreted_batch_ndims=len(event_shape))
+    return distrax.Transformed(base, flow), layers
+
+
+def make_flow_model_rqs(distrax, event_shape, num_layers, hidden_sizes, bins, lo, hi, base_kind, rng, final_std):
+    """src/maf_toy_densities.py:74-111 / src/maf_mnist.py:52-89."""
+    mask = np.arange(0, np.prod(event_shape)) % 2
+    mask = np.reshape(mask, event_shape).astype(bool)
+    P = 3 * bins + 1
+
+    def bijector_fn(params):
+        return distrax.RationalQuadraticSpline(params, range_min=lo, range_max=hi)
+
+    layers = []
+    for _ in range(num_layers):
+        layers.append(distrax.MaskedCoupling(
+            mask=mask, bijector=bijector_fn,
+            conditioner=distrax.make_conditioner(event_shape, hidden_sizes, P, per_dim=True, rng=rng,
+                                                 final_std=final_std)))
+        mask = np.logical_not(mask)
+    flow = distrax.Inverse(distrax.Chain(layers))
+    if base_kind == "normal":
+        inner = distrax.Normal(loc=np.zeros(event_shape), scale=np.ones(event_shape))
+    else:
+        inner = distrax.Uniform(low=np.zeros(event_shape), high=np.ones(event_shape))
+    return distrax.Transformed(distrax.Independent(inner, reinterpreted_batch_ndims=len(event_shape)), flow), layers
+
+
+def spec_of(layers, kind, event_size, **kw):
+    masks = [l.mask.reshape(-1) for l in layers]
+    return O.FlowSpec(kind, event_size, [l.conditioner.linears for l in layers], masks, **kw)
+
+
+def test_real_nvp_toy_script(distrax):
+    rng = np.random.default_rng(42)
+    model, layers = make_flow_model_affine(distrax, (2,), 8, [64, 64], rng, 0.02)
+    spec = spec_of(layers, "affine", 2)
+    x = O.make_inputs("banana", 4096)
+    lp = model.log_prob(x)                      # log_prob.apply(params, batch)
+    ref = O.log_prob(spec, x)
+    assert lp.shape == (4096,)
+    assert (np.abs(lp - ref) <= tol(ref)).all()
+    assert abs(model.nll(x) - O.nll(spec, x)) <= 1e-5     # eval_fn
+    assert abs(-np.mean(lp.astype(np.float64)) - model.nll(x)) <= 1e-9
+    # sample.apply: base draw on the host, Chain.inverse on the GPU
+    s = model.sample(seed=7, sample_shape=(1000,))
+    z = model.distribution.sample(seed=7, sample_shape=(1000,))
+    assert s.shape == (1000, 2)
+    assert (np.abs(s - O.sample_from_z(spec, z)) <= tol(O.sample_from_z(spec, z))).all()
+    # bijector protocol on the pieces
+    chain = model.bijector.bijector
+    y, ld = chain.forward_and_log_det(x)
+    yr, ldr = O.chain_forward(spec, x)
+    assert (np.abs(y - yr) <= tol(yr)).all() and (np.abs(ld - ldr) <= tol(ldr)).all()
+    xi, ldi = model.bijector.forward_and_log_det(y)       # Inverse swaps directions
+    assert np.abs(xi - x).max() <= 2e-5 * np.abs(x).max()
+    y1, ld1 = layers[3].forward_and_log_det(x)            # one MaskedCoupling
+    y1r, ld1r = O.coupling_layer(spec, 3, x, False)
+    assert (np.abs(y1 - y1r) <= tol(y1r)).all() and (np.abs(ld1 - ld1r) <= tol(ld1r)).all()
+    assert np.array_equal(layers[3].forward(x), y1)
+    assert np.array_equal(layers[3].forward_log_det_jacobian(x), ld1)
+    # leading batch dims are kept
+    lp3 = model.log_prob(x.reshape(64, 64, 2))
+    assert lp3.shape == (64, 64) and np.array_equal(lp3.reshape(-1), lp)
+
+
+def test_identity_at_init_known_answer(distrax):
+    """Freshly initialised flow (zero final Linear) is the identity: log_prob == base log_prob."""
+    model, _ = make_flow_model_affine(distrax, (2,), 8, [64, 64], np.random.default_rng(1), 0.0)
+    x = O.make_inputs("energy1", 1024)
+    lp = model.log_prob(x)
+    base = model.distribution.log_prob(x)
+    assert np.abs(lp - base).max() <= 4e-6   # two kernels, one ulp apart at |log_prob| ~ 16
+    ref = -0.5 * (x.astype(np.float64) ** 2).sum(-1) - np.log(2 * np.pi)
+    assert (np.abs(base - ref) <= tol(ref)).all()
+
+
+def test_swapped_split_and_param_updates(distrax):
+    rng = np.random.default_rng(3)
+    event_shape = (2,)
+    mask = (np.arange(2) % 2).astype(bool)
+
+    def swapped_fn(params):
+        log_scale, shift = np.split(params, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+
+    cond = distrax.make_conditioner(event_shape, [64, 64], 2, rng=rng, final_std=0.05)
+    layer = distrax.MaskedCoupling(mask=mask, bijector=swapped_fn, conditioner=cond)
+    x = O.make_inputs("energy2", 512)
+    W, b = cond.linears[-1]
+    swapped = list(cond.linears[:-1]) + [(W[:, ::-1], b[::-1])]
+    spec = O.FlowSpec("affine", 2, [swapped], [mask])
+    y, ld = layer.forward_and_log_det(x)
+    yr, ldr = O.coupling_layer(spec, 0, x, False)
+    assert (np.abs(y - yr) <= tol(yr)).all() and (np.abs(ld - ldr) <= tol(ldr)).all()
+    # new parameters are picked up (handle rebuilt on version change)
+    cond.set_params([(w * 0.5, bb) for w, bb in cond.linears])
+    y2, _ = layer.forward_and_log_det(x)
+    assert np.abs(y2 - y).max() > 1e-4
+
+
+def test_unsupported_structures_fail_loudly(distrax):
+    mask = (np.arange(2) % 2).astype(bool)
+    with pytest.raises(NotImplementedError):
+        distrax.MaskedCoupling(mask=mask, bijector=lambda p: None, conditioner=lambda x: x)
+
+    def tanh_fn(params):
+        shift, log_scale = np.split(params, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, log_scale=np.tanh(log_scale))
+
+    cond = distrax.make_conditioner((2,), [64, 64], 2)
+    layer = distrax.MaskedCoupling(mask=mask, bijector=tanh_fn, conditioner=cond)
+    with pytest.raises(NotImplementedError):
+        layer.forward_and_log_det(np.zeros((4, 2), np.float32))
+    with pytest.raises(NotImplementedError):
+        distrax.ScalarAffine(shift=0.0, log_scale=0.0).forward_and_log_det(np.zeros(3))
+    with pytest.raises(ValueError):
+        distrax.RationalQuadraticSpline(np.zeros(5), 0.0, 1.0)
+    with pytest.raises(ValueError):
+        distrax.RationalQuadraticSpline(np.zeros(7), 1.0, 0.0)
+
+
+def test_maf_toy_script(distrax):
+    rng = np.random.default_rng(5)
+    model, layers = make_flow_model_rqs(distrax, (2,), 8, [64, 64], 12, -8.0, 8.0, "normal", rng, 0.05)
+    spec = spec_of(layers, "rqs", 2, num_bins=12, range_min=-8.0, range_max=8.0)
+    x = O.make_inputs("gaussian_blobs", 4096)
+    lp = model.log_prob(x)
+    ref = O.log_prob(spec, x)
+    # spline chains amplify float32 rounding: allow 4x the float32 restatement's own worst error
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert (np.abs(lp - ref) <= np.maximum(tol(ref), 4 * e32)).all()
+    assert abs(model.nll(x) - O.nll(spec, x)) <= 1e-5 * max(1.0, abs(O.nll(spec, x)))
+    s = model.sample(seed=11, sample_shape=500)
+    z = model.distribution.sample(seed=11, sample_shape=500)
+    sr = O.sample_from_z(spec, z)
+    e32 = np.abs(O.sample_from_z(spec, z, np.float32) - sr).max()
+    assert (np.abs(s - sr) <= np.maximum(tol(sr), 4 * e32)).all()
+
+
+def test_maf_mnist_script_shapes(distrax):
+    rng = np.random.default_rng(6)
+    shape = (28, 28, 1)
+    model, layers = make_flow_model_rqs(distrax, shape, 2, [512, 512, 512], 8, 0.0, 1.0, "uniform", rng, 0.2)
+    spec = spec_of(layers, "rqs", 784, num_bins=8, range_min=0.0, range_max=1.0, base="uniform01")
+    x = O.make_inputs("mnist_like", 64).reshape(64, 28, 28, 1)   # prepare_data(batch): k / 256
+    lp = model.log_prob(x)
+    ref = O.log_prob(spec, x.reshape(64, 784))
+    assert lp.shape == (64,)
+    assert (np.abs(lp - ref) <= tol(ref)).all()
+
+
+def test_real_nvp_py_free_functions(distrax):
+    from normalizing_flows_amd import real_nvp as R
+    params, fns_config = R.init_nvp_chain(n=8)
+    flips = [flip for _, flip in fns_config]
+    assert flips == [False, True] * 4
+    # distinct layers so that order matters
+    rng = np.random.default_rng(534)
+    params = [[[(rng.standard_normal(W.shape) * 0.1).astype(np.float32), (rng.standard_normal(b.shape) * 0.05).astype(np.float32)]
+               for W, b in net] for net in params]
+    y = O.make_inputs("energy2", 4096)
+    lp = R.log_prob_nvp_chains(params, fns_config, R.log_prob_N01, y)
+    ref = O.a_log_prob_chain(params, flips, y)
+    assert (np.abs(lp - ref) <= tol(ref)).all()
+    assert abs(R.loss(params, fns_config, y) - O.a_nll(params, flips, y)) <= 1e-5
+    x = R.sample_nvp_chain(params, fns_config, R.sample_N01, 1000, 7809)
+    z = R.sample_N01(1000, 7809)
+    xr = O.a_sample_chain_from_z(params, flips, z)
+    assert (np.abs(x - xr) <= tol(xr)).all()
+    # single-layer functions
+    f1 = R.forward_nvp(params[2], R.shift_and_log_scale_fn, y, flip=False)
+    assert (np.abs(f1 - O.a_forward_layer(params[2], y, False)) <= 1e-5 * np.maximum(1, np.abs(f1))).all()
+    xi, ls = R.inverse_nvp(params[3], R.shift_and_log_scale_fn, y, flip=True)
+    xr, lsr = O.a_inverse_layer(params[3], y, True)
+    assert (np.abs(xi - xr) <= tol(xr)).all() and (np.abs(ls - lsr) <= tol(lsr)).all()
+    shift, log_scale = R.shift_and_log_scale_fn(params[0], y[:, :1])
+    sr, lr = O.a_shift_and_log_scale(params[0], y[:, :1])
+    assert (np.abs(shift - sr) <= tol(sr)).all() and (np.abs(log_scale - lr) <= tol(lr)).all()
+    lp1 = R.log_prob_nvp(params[0], R.shift_and_log_scale_fn, R.log_prob_N01, y, flip=False)
+    x0, ls0 = O.a_inverse_layer(params[0], y, False)
+    ref1 = O.a_base_log_prob(x0) - ls0.sum(-1)
+    assert (np.abs(lp1 - ref1) <= tol(ref1)).all()
+    with pytest.raises(NotImplementedError):
+        R.log_prob_nvp_chains(params, fns_config, lambda v: v.sum(-1), y)
