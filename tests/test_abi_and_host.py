@@ -1,0 +1,229 @@
+"""CPU-side checks: the C ABI library loads and exports what include/nf_hip.h declares,
+host-side logic (packing, lowering, sharding), and that the product has no CPU fallback."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "nf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(nf_lib):
+    from normalizing_flows_amd import _lib
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(nf_lib, n), f"{n} is declared in include/nf_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes table and header disagree"
+    assert nf_lib.nf_abi_version() == 1
+
+
+def test_desc_struct_layout_matches_header():
+    from normalizing_flows_amd import _lib
+    # 6 + 8 int32, then 3 int32, then 4 floats: no padding expected
+    assert C.sizeof(_lib.FlowDesc) == 4 * (5 + 8 + 4 + 4)
+    assert _lib.FlowDesc.hidden.offset == 20 and _lib.FlowDesc.rqs_range_min.offset == 68
+
+
+def test_no_device_means_loud_failure(nf_lib):
+    """Without a GPU nothing computes: create fails with NF_ERR_NO_DEVICE, never a CPU path."""
+    from normalizing_flows_amd import _lib, flow
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=2, hidden=(64, 64))
+    with pytest.raises(_lib.NFError) as e:
+        flow.CouplingFlow(cfg)
+    assert e.value.status == -4
+    h = C.c_void_p()
+    d = cfg.to_desc()
+    assert nf_lib.nf_flow_create(C.byref(d), C.byref(h)) == -4 and not h.value
+    import normalizing_flows_amd as distrax
+    base = distrax.Independent(distrax.Normal(np.zeros(2), np.ones(2)), 1)
+    with pytest.raises(_lib.NFError):
+        base.log_prob(np.zeros((3, 2), np.float32))
+
+
+def test_desc_validation_and_weight_count(nf_lib):
+    from normalizing_flows_amd import _lib, flow
+    n = C.c_size_t()
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
+    d = cfg.to_desc()
+    assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == 0 and n.value == 8 * 4482
+    cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=784, num_layers=6, hidden=(512, 512, 512),
+                          rqs_bins=8, base=_lib.BASE_UNIFORM01)
+    d = cfg.to_desc()
+    assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == 0 and n.value == 6 * 10982032
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,), first_mask_parity=0)
+    d = cfg.to_desc()
+    assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == 0 and n.value == 8 * 18
+    for bad in (dict(event_dim=1), dict(num_layers=0), dict(kind=7), dict(activation=5), dict(base=9),
+                dict(first_mask_parity=2)):
+        base = dict(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=2, hidden=(64, 64))
+        base.update(bad)
+        d = flow.FlowConfig(**base).to_desc()
+        assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == -1, bad
+        assert nf_lib.nf_last_error()
+    d = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=3, num_layers=2, hidden=(4,)).to_desc()
+    assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == -1
+    for bad in (dict(rqs_bins=0), dict(rqs_range_min=1.0, rqs_range_max=0.0), dict(rqs_min_knot_slope=1.5),
+                dict(rqs_bins=4, rqs_min_bin_size=0.5)):
+        base = dict(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=2, hidden=(64, 64), rqs_bins=4)
+        base.update(bad)
+        d = flow.FlowConfig(**base).to_desc()
+        assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == -1, bad
+    d = cfg.to_desc()
+    d.abi_version = 99
+    assert nf_lib.nf_flow_weight_count(C.byref(d), C.byref(n)) == -1
+
+
+def test_pack_weights_order_and_checks():
+    from normalizing_flows_amd import _lib, flow
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=2, hidden=(3,))
+    layers = []
+    v = 0
+    for _ in range(2):
+        W0 = np.arange(v, v + 6, dtype=np.float32).reshape(2, 3); v += 6
+        b0 = np.arange(v, v + 3, dtype=np.float32); v += 3
+        W1 = np.arange(v, v + 6, dtype=np.float32).reshape(3, 2); v += 6
+        b1 = np.arange(v, v + 2, dtype=np.float32); v += 2
+        layers.append([(W0, b0), (W1, b1)])
+    packed = flow.pack_weights(cfg, layers)
+    assert np.array_equal(packed, np.arange(34, dtype=np.float32))
+    with pytest.raises(ValueError):
+        flow.pack_weights(cfg, layers[:1])
+    with pytest.raises(ValueError):
+        flow.pack_weights(cfg, [[(np.zeros((2, 4)), np.zeros(4)), (np.zeros((4, 2)), np.zeros(2))]] * 2)
+
+
+def test_conditioner_and_haiku_param_mapping():
+    import normalizing_flows_amd as distrax
+    c = distrax.make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(0))
+    assert c.hidden_sizes == (64, 64) and c.in_size == 2 and c.out_size == 2
+    assert np.all(c.linears[-1][0] == 0) and np.all(c.linears[-1][1] == 0)       # zero-init final Linear
+    assert abs(c.linears[1][0].std() - 1 / 8 * 0.88) < 0.02 and np.abs(c.linears[1][0]).max() <= 2 / 8 + 1e-6
+    c = distrax.make_conditioner((28, 28, 1), [16], 25, per_dim=True)
+    assert c.out_size == 19600 and c.params_per_dim == 25
+    with pytest.raises(NotImplementedError):
+        c(np.zeros((1, 784)))
+    hk = {}
+    for k in range(3):
+        pre = "mlp" if k == 0 else f"mlp_{k}"
+        lin = "linear" if k == 0 else f"linear_{k}"
+        hk[f"{pre}/~/linear_0"] = {"w": np.full((2, 4), k), "b": np.zeros(4)}
+        hk[f"{pre}/~/linear_1"] = {"w": np.full((4, 4), k + 10), "b": np.zeros(4)}
+        hk[lin] = {"w": np.full((4, 2), k + 20), "b": np.zeros(2)}
+    layers = distrax.layers_from_haiku_params(hk)
+    assert len(layers) == 3 and [len(l) for l in layers] == [3, 3, 3]
+    assert layers[2][0][0][0, 0] == 2 and layers[2][1][0][0, 0] == 12 and layers[1][2][0][0, 0] == 21
+    with pytest.raises(ValueError):
+        distrax.layers_from_haiku_params({"conv": {"w": 0, "b": 0}})
+
+
+def test_lowering_recognises_reference_structures_without_a_gpu():
+    import normalizing_flows_amd as distrax
+    from normalizing_flows_amd import _lib
+    from normalizing_flows_amd.bijectors import lower_for_log_prob
+    mask = (np.arange(2) % 2).astype(bool)
+
+    def affine_fn(p):
+        shift, log_scale = np.split(p, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+
+    layer = distrax.MaskedCoupling(mask, affine_fn, distrax.make_conditioner((2,), [64, 64], 2))
+    sig = layer.signature()
+    assert sig.kind == _lib.KIND_AFFINE_MASKED and sig.parity == 1 and sig.hidden == (64, 64)
+    layer0 = distrax.MaskedCoupling(~mask, affine_fn, distrax.make_conditioner((2,), [64, 64], 2))
+    assert layer0.signature().parity == 0
+
+    def rqs_fn(p):
+        return distrax.RationalQuadraticSpline(p, range_min=-8.0, range_max=8.0)
+
+    rl = distrax.MaskedCoupling(mask, rqs_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    s = rl.signature()
+    assert s.kind == _lib.KIND_RQS_MASKED and s.rqs[:3] == (12, -8.0, 8.0)
+    chain = distrax.Chain([layer, layer0])
+    inv = distrax.Inverse(chain)
+    assert lower_for_log_prob(inv) == (chain, _lib.DIR_CHAIN_FORWARD)
+    assert lower_for_log_prob(chain) == (chain, _lib.DIR_CHAIN_INVERSE)
+    assert lower_for_log_prob(distrax.Inverse(inv))[1] == _lib.DIR_CHAIN_INVERSE
+    with pytest.raises(NotImplementedError):                      # masks must alternate
+        distrax.Chain([layer, layer]).lowered()
+    with pytest.raises(NotImplementedError):
+        distrax.MaskedCoupling(np.array([True, True]), affine_fn,
+                               distrax.make_conditioner((2,), [64, 64], 2)).signature()
+
+    class Rotation(distrax.Bijector):        # the reference's README example subclasses Bijector
+        def __init__(self):
+            super().__init__(event_ndims_in=1, event_ndims_out=1)
+
+        def forward_and_log_det(self, x):
+            return x, 0.0
+
+    r = Rotation()
+    assert r.event_ndims_in == 1 and r.forward(3.0) == 3.0
+    with pytest.raises(NotImplementedError):
+        r.inverse(1.0)
+    with pytest.raises(NotImplementedError):
+        lower_for_log_prob(r)
+    with pytest.raises(ValueError):
+        distrax.Chain([])
+    base = distrax.Independent(distrax.Normal(np.zeros(2), np.ones(2)), reinterpreted_batch_ndims=1)
+    assert base.event_shape == (2,) and base._base_code() == _lib.BASE_STD_NORMAL
+    assert distrax.Independent(distrax.Uniform(np.zeros((28, 28, 1)), np.ones((28, 28, 1))), 3)._base_code() == 1
+    assert distrax.Independent(distrax.Normal(np.zeros(2), 2 * np.ones(2)), 1)._base_code() is None
+    assert distrax.MultivariateNormalDiag(np.zeros(2), np.ones(2))._base_code() == 0
+    z = base.sample(seed=3, sample_shape=(5,))
+    assert z.shape == (5, 2) and np.array_equal(z, base.sample(seed=3, sample_shape=(5,)))
+    with pytest.raises(ValueError):
+        distrax.Transformed(distrax.Normal(0.0, 1.0), chain)
+
+
+def test_shard_rows():
+    from normalizing_flows_amd import shard_rows
+    for rows, world in [(1 << 23, 8), (4096, 2), (4097, 2), (7, 4), (0, 3), (1, 2), (1000003, 8)]:
+        spans = [shard_rows(rows, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == rows
+        for (a, b), (c, d) in zip(spans[:-1], spans[1:]):
+            assert b == c and a % 2 == 0 and c % 2 == 0
+        sizes = [b - a for a, b in spans]
+        assert max(sizes[:-1] or [0]) - min(sizes[:-1] or [0]) <= 2
+    assert [shard_rows(1 << 23, 8, r)[1] - shard_rows(1 << 23, 8, r)[0] for r in range(8)] == [1 << 20] * 8
+    with pytest.raises(ValueError):
+        shard_rows(10, 2, 2)
+
+
+def test_product_never_touches_the_oracle_or_a_cpu_path():
+    pkg = os.path.join(ROOT, "normalizing_flows_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+                assert "import torch" not in text and "import jax" not in text, f
+
+
+def test_sharded_nll_gloo_world2():
+    """N > 1 host path on CPU: two gloo ranks, each sums ITS rows (here via the oracle, which
+    stands in for the GPU's local sum), one all-reduce of one float64, same NLL as one rank."""
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    vals = [float(o.strip().splitlines()[-1].split()[-1]) for o in outs]
+    assert vals[0] == vals[1]
+    from oracle import flows_np as O
+    spec = O.make_affine_spec(4, final_std=0.02)
+    x = O.make_inputs("banana", 4097)
+    assert abs(vals[0] - O.nll(spec, x)) < 1e-12

@@ -442,3 +442,39 @@ def test_base_log_prob_standalone(nfa):
     _lib.check(lib.nf_base_log_prob(_lib.BASE_STD_NORMAL, 2, x.ctypes.data_as(C.c_void_p), 1000,
                                     out.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
     assert_close(out, O.a_base_log_prob(x), "standalone normal base")
+
+
+# ------------------------------------------------------------------ committed golden vectors
+def test_golden_vectors(nfa):
+    import os
+    from normalizing_flows_amd import _lib
+    from test_oracle_kat import GOLD, unflat_affine
+    for name in ("affine_l4_banana", "affine_l8_energy3"):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        L = int(g["num_layers"])
+        cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=L, hidden=(64, 64))
+        f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], L))
+        assert_close(f.log_prob(g["x"]), g["log_prob"], name)
+        z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, g["x"])
+        assert_close(z, g["z"], name + " z")
+        assert_close(ld, g["logdet"], name + " logdet")
+        assert abs(f.nll(g["x"]) - float(g["nll"])) <= 1e-5
+    g = np.load(os.path.join(GOLD, "split_l8_energy2.npz"))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
+                         activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
+    f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], 8, hidden=(4,), D=1, out=2))
+    assert_close(f.log_prob(g["x"]), g["log_prob"], "golden split")
+    y, _ = f.chain_apply(_lib.DIR_FIRST_TO_LAST_FORWARD, g["x"])
+    assert_close(y, g["sample_from_x"], "golden split sample")
+    g = np.load(os.path.join(GOLD, "rqs_l8_blobs.npz"))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), rqs_bins=12,
+                         rqs_range_min=-8.0, rqs_range_max=8.0)
+    f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], 8, out=74))
+    assert_close(f.log_prob(g["x"]), g["log_prob"], "golden rqs", 3e-5)
+    g = np.load(os.path.join(GOLD, "affine_hand_case.npz"))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=1, hidden=(2, 2))
+    f = nfa.CouplingFlow(cfg, [[(g["W1"], g["b1"]), (g["W2"], g["b2"]), (g["W3"], g["b3"])]])
+    y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, g["x"])
+    assert_close(y, g["y"], "hand case y")
+    assert_close(ld, g["logdet"], "hand case logdet")
+    assert_close(f.log_prob(g["x"]), g["log_prob"], "hand case log_prob")
