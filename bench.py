@@ -32,29 +32,40 @@ FLOP_PER_EVAL_L8 = 69632       # L * 2 * (2*64 + 64*64 + 64*2), 
 BYTES_PER_EVAL = 12            # 8 B in (x[2] f32) + 4 B out (log_prob f32)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(spec, density):
-    """The NumPy float32 restatement (oracle) timed on this host: a reported
-    baseline ("port"), not the target.  Bounded sample of the same workload."""
+    """The C restatement of the oracle (oracle/nf_oracle.c, OpenMP over the batch) timed on
+    this host's cores: a reported baseline ("port"), not the target.  Bounded sample of the
+    same workload (about 10 s)."""
+    from oracle import c_oracle as CO
     from oracle import flows_np as O
-    rows = 1 << 18
+    rows = 1 << 20
     x = O.make_inputs(density, rows)
-    O.log_prob(spec, x[:4096], np.float32)  # warm
+    threads = min(CO.max_threads(), usable_cpus())
+    CO.affine_masked_log_prob(spec, x[:1 << 16], threads)  # warm
     t0 = time.perf_counter()
     reps = 0
     while True:
-        O.log_prob(spec, x, np.float32)
+        CO.affine_masked_log_prob(spec, x, threads)
         reps += 1
-        if time.perf_counter() - t0 > 8.0:
+        if time.perf_counter() - t0 > 10.0:
             break
     dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
     return {"value": rows * reps / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
-            "sample": f"NumPy float32 restatement (oracle/flows_np.py), {reps} x 2^18 rows of the same "
-                      f"8-layer flow on {density}; host has {os.cpu_count()} logical CPUs"}
+            "sample": f"C/OpenMP float32 restatement (oracle/nf_oracle.c), {reps} x 2^20 rows of the same "
+                      f"{len(spec.layers)}-layer flow on {density}, {threads} OpenMP threads "
+                      f"(host reports {os.cpu_count()} logical CPUs)"}
 
 
 def main():

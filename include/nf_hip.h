@@ -188,6 +188,11 @@ int nf_nll_result(nf_flow* flow, int slot, double* out_nll);
 int nf_timer_start(nf_flow* flow);
 int nf_timer_stop(nf_flow* flow, float* out_ms); /* synchronises on the stop event */
 
+/* Diagnostic, not part of the path: streams a device [rows, 2] float32 matrix with the
+   hot path's access shape so that rocprofv3's FETCH_SIZE can be calibrated on a known byte
+   count (profiles/README.md). */
+int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
 /* librccl.so.1 is dlopen'ed on first use; a build box without it still loads
    libnf_hip.so.  id is an ncclUniqueId (128 bytes) made on rank 0 and handed to

@@ -536,6 +536,13 @@ int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, floa
   return s;
 }
 
+int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev) {
+  if (!x_dev || !out_dev || rows < 1) { set_error("bad argument"); return NF_ERR_INVALID; }
+  NF_TRY(generic::launch_debug_read_f2(x_dev, rows, out_dev, nullptr));
+  NF_HIP(hipDeviceSynchronize());
+  return NF_OK;
+}
+
 int nf_timer_start(nf_flow* f) {
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   NF_HIP(hipEventRecord(f->ev0, f->stream));

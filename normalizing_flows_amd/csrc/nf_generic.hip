@@ -322,6 +322,26 @@ int launch_base_log_prob(const float* z, const float* ld, float* lp, double* blo
   return NF_OK;
 }
 
+// Streaming read of a [rows, 2] float32 matrix with the hot path's access shape (one float2
+// per lane); exists to calibrate rocprofv3's FETCH_SIZE on a known byte count
+// (MI355X_MICROARCH.md, HBM section: widths other than 16 B/lane are uncalibrated).
+__global__ __launch_bounds__(256) void debug_read_f2_kernel(const float2* __restrict__ x, long long rows,
+                                                           float* __restrict__ out) {
+  float acc = 0.f;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    const float2 v = x[r];
+    acc += v.x + v.y;
+  }
+  if (acc == 123.456f) out[0] = acc;  // keeps the loads alive, practically never stores
+}
+
+int launch_debug_read_f2(const float* x, long long rows, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(debug_read_f2_kernel, dim3(2048), dim3(256), 0, stream,
+                     reinterpret_cast<const float2*>(x), rows, out);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // ------------------------------------------------------------------------
 // host side: weights and the layer walk
 // ------------------------------------------------------------------------

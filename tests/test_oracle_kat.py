@@ -245,3 +245,19 @@ def test_synthetic_inputs_match_generator_statistics():
     assert abs(e[:, 0].min() + 1.5 * np.pi) < 1e-3 and abs((e[:, 1] - np.sin(np.pi * e[:, 0] / 2)).std() - 0.5) < 0.01
     m = O.make_inputs("mnist_like", 10)
     assert m.shape == (10, 784) and m.min() >= 0 and m.max() < 1 and np.all(m * 256 == np.round(m * 256))
+
+
+def test_c_restatement_matches_numpy_oracle():
+    """oracle/nf_oracle.c (the cpu_baseline "port") against oracle/flows_np.py."""
+    from oracle import c_oracle as CO
+    spec = O.make_affine_spec(8, final_std=0.02)
+    x = O.make_inputs("energy3", 5000)
+    ref = O.log_prob(spec, x)
+    got = CO.affine_masked_log_prob(spec, x, 2)
+    assert (np.abs(got - ref) <= 3e-5 * np.maximum(1, np.abs(ref))).all()
+    spec5 = O.make_affine_spec(3, event_size=5, hidden=(33,), final_std=0.03, first_parity=0)
+    x5 = RNG.standard_normal((300, 5)).astype(np.float32)
+    assert np.abs(CO.affine_masked_log_prob(spec5, x5) - O.log_prob(spec5, x5)).max() < 2e-5
+    params, flips = O.make_a_params(8)
+    y = O.make_inputs("energy2", 3000)
+    assert np.abs(CO.affine_split_log_prob(params, flips, y) - O.a_log_prob_chain(params, flips, y)).max() < 3e-5
