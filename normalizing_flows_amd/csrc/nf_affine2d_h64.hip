@@ -15,20 +15,21 @@
 //     units 8(r>>2)+4h+(r&3) of M-tile m in registers r.
 //   * The first Linear has ONE live input (the masked event dim is zero), so
 //     its output h1[k] = relu(x_c*w1[k]+b1[k]) is produced directly in the B
-//     operand's register layout: one v_fma + one v_max per k-step, no LDS
-//     round trip for activations.
+//     operand's register layout by ONE v_fma with the clamp bit per k-step
+//     (see kReluShift), no LDS round trip for activations.
 //   * b2 enters as the C operand of the first k-step.  The last Linear (64->2)
 //     is lane-local: each lane reduces its 32 units against W3 rows held in the
 //     accumulator's order, and one v_permlane32_swap adds the two half-waves.
 //   * All layers' weights sit in LDS (17,680 B per layer, pre-arranged on the
 //     host in operand order, so every LDS read is a contiguous ds_read_b64 /
-//     b128 or a broadcast); one 512-thread workgroup per CU, two waves per
-//     SIMD so one wave's epilogue overlaps the other's MFMA stream.
+//     b128 or a broadcast); one 1024-thread workgroup per CU, four waves per SIMD.
 //   * HBM traffic is 8 B in + 4..12 B out per sample: the kernel is bound by
 //     the f32 MFMA rate, not by HBM.
 #include "nf_internal.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace nf {
@@ -37,6 +38,12 @@ namespace affine2d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ host pack
+// The first Linear is stored scaled by 2^-kReluShift and W2 by 2^+kReluShift (both exact
+// in float32), so that relu(x*w1+b1) can be taken with the v_fma's clamp-to-[0,1] bit:
+// clamp((x*w1+b1) * 2^-64) == relu(x*w1+b1) * 2^-64 for every pre-activation below 2^64,
+// and the products W2*h1 are bit-identical to the unscaled ones.
+constexpr int kReluShift = 64;
+
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2,
                 const float* W3, const float* b3, int cond_dim, float* img) {
   memset(img, 0, sizeof(float) * kLayerFloats);
@@ -45,11 +52,11 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
       for (int m = 0; m < 2; ++m) {
         const int k = 2 * s + (lane >> 5);
         const int u = 32 * m + (lane & 31);
-        img[kA2 + (s * 64 + lane) * 2 + m] = W2[k * kHidden + u];
+        img[kA2 + (s * 64 + lane) * 2 + m] = ldexpf(W2[k * kHidden + u], kReluShift);
       }
   for (int k = 0; k < 64; ++k) {
-    img[kW1B1 + 2 * k + 0] = W1[cond_dim * kHidden + k];
-    img[kW1B1 + 2 * k + 1] = b1[k];
+    img[kW1B1 + 2 * k + 0] = ldexpf(W1[cond_dim * kHidden + k], -kReluShift);
+    img[kW1B1 + 2 * k + 1] = ldexpf(b1[k], -kReluShift);
   }
   for (int h = 0; h < 2; ++h)
     for (int m = 0; m < 2; ++m)
@@ -87,25 +94,48 @@ __device__ __forceinline__ f32x16 lds_f32x16(const float* p) {
   return v;
 }
 
+// exp(x) for the affine map: 2^(x*log2(e)) with the product carried in two floats, so the
+// hardware exp2 (v_exp_f32, ~1 ulp) sees an exactly rounded argument.  About 1.5 ulp overall;
+// overflow -> +inf and underflow -> 0 come from v_exp_f32 itself.
+__device__ __forceinline__ float exp_f32(float x) {
+  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float hi = x * kLog2eHi;
+  const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return fmaf(e, lo * kLn2, e);
+}
+
 // T = 32-sample column tiles a wave carries through the chain at once.
-template <int T>
-__global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
+// WAVES = waves per workgroup; one workgroup per CU (LDS holds every layer), WAVES/4 per SIMD.
+// INV = 0: y_t = x_t*exp(ls)+shift, logdet += ls;  1: x_t = (y_t-shift)*exp(-ls), logdet -= ls.
+//
+// Measured on MI355X (profiles/r01): the f32 MFMA and the f32 VALU do NOT overlap on a SIMD
+// (SQ_VALU_MFMA_BUSY_CYCLES + 4 * SQ_ACTIVE_INST_VALU ~= kernel cycles; hiding the last
+// Linear inside the MFMA stream by software pipelining changed nothing), so the kernel's
+// efficiency is MFMA cycles / (MFMA cycles + VALU issue cycles): every VALU instruction
+// removed from the per-tile stream is worth ~4 cycles against 64 per MFMA.  Hence
+//   * relu of the first Linear rides on the v_fma's clamp bit (one VALU per k-step and tile),
+//   * the affine map uses the 6-instruction exp above, the direction is a template parameter,
+//   * four waves per SIMD (T = 2).
+template <int T, int WAVES, int INV>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ChainIO& io = p.io;
   const int tid = threadIdx.x;
   const int nlay = io.layer_end - io.layer_begin;
+  constexpr int NTHREADS = WAVES * 64;
 
   // stage the images of the layers this launch walks (contiguous in wimg)
   {
     const float4* src = reinterpret_cast<const float4*>(p.wimg + (size_t)io.layer_begin * kLayerFloats);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int n4 = nlay * (kLayerFloats / 4);
-    for (int q = tid; q < n4; q += kThreads) dst[q] = src[q];
+    for (int q = tid; q < n4; q += NTHREADS) dst[q] = src[q];
   }
   __syncthreads();
 
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31;  // sample column inside a tile
   const int h = lane >> 5;  // half-wave: k parity (operands), unit group (accumulator)
   const long long rows = io.rows;
@@ -114,7 +144,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
 
   double wave_sum = 0.0;
 
-  for (long long g = (long long)blockIdx.x * 8 + wave; g < groups; g += (long long)gridDim.x * 8) {
+  for (long long g = (long long)blockIdx.x * WAVES + wave; g < groups; g += (long long)gridDim.x * WAVES) {
     const int l_first = io.descending ? io.layer_end - 1 : io.layer_begin;
     const int c_first = (p.first_mask_parity + l_first) & 1;  // dim the first walked layer conditions on
 
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
         const float2 wb = w1b1[0];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const float b = fmaxf(fmaf(xc[t], wb.x, wb.y), 0.f);
+          const float b = __builtin_amdgcn_fmed3f(fmaf(xc[t], wb.x, wb.y), 0.f, 1.f);  // v_fma ... clamp
           acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
         }
@@ -155,7 +185,8 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
         const float2 wb = w1b1[2 * s];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const float b = fmaxf(fmaf(xc[t], wb.x, wb.y), 0.f);
+          // relu(x*w1+b1) * 2^-64 in one instruction (see kReluShift)
+          const float b = __builtin_amdgcn_fmed3f(fmaf(xc[t], wb.x, wb.y), 0.f, 1.f);
           acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[t][1], 0, 0, 0);
         }
@@ -182,11 +213,11 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
         const float shift = add_halves(ps) + b3s;
         const float ls = add_halves(pl) + b3l;
         float nt;
-        if (io.inverse_op) {
-          nt = (xt[t] - shift) * expf(-ls);
+        if (INV) {
+          nt = (xt[t] - shift) * exp_f32(-ls);
           ld[t] -= ls;
         } else {
-          nt = fmaf(xt[t], expf(ls), shift);
+          nt = fmaf(xt[t], exp_f32(ls), shift);
           ld[t] += ls;
         }
         // masks alternate: the dim just transformed conditions the next layer
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
   }
 
   if (io.block_sums) {
-    // every wave reaches this point: reduce lanes, then the 8 waves, in a fixed order
+    // every wave reaches this point: reduce lanes, then the waves, in a fixed order
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_down(wave_sum, off);
     __syncthreads();  // all waves are done with the weight images
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
     __syncthreads();
     if (tid == 0) {
       double s = 0.0;
-      for (int w = 0; w < 8; ++w) s += red[w];
+      for (int w = 0; w < WAVES; ++w) s += red[w];
       io.block_sums[blockIdx.x] = s;
     }
   }
@@ -237,17 +268,33 @@ __global__ __launch_bounds__(kThreads, 2) void chain_kernel(Params p) {
 
 int max_grid() { return 256; }
 
-template <int T>
+template <int T, int WAVES, int INV>
 static int launch_t(const Params& p, int grid, size_t lds_bytes, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T>),
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(chain_kernel<T>, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+  hipLaunchKernelGGL((chain_kernel<T, WAVES, INV>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
+}
+
+template <int T, int WAVES>
+static int launch_dir(const Params& p, int grid, size_t lds_bytes, hipStream_t stream) {
+  return p.io.inverse_op ? launch_t<T, WAVES, 1>(p, grid, lds_bytes, stream)
+                         : launch_t<T, WAVES, 0>(p, grid, lds_bytes, stream);
+}
+
+// Development knob: NF_AFFINE2D_TUNE="T,WAVES" overrides the shipped geometry
+// (profiles/ab_affine2d.py A/Bs variants inside one process).
+struct Tune { int T, waves; };
+static Tune read_tune() {
+  Tune t = {2, 16};
+  const char* e = getenv("NF_AFFINE2D_TUNE");
+  if (e) sscanf(e, "%d,%d", &t.T, &t.waves);
+  return t;
 }
 
 int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid_cap,
@@ -257,25 +304,25 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
     set_error("affine2d launch walks %d layers, at most %d fit in LDS", nlay, kMaxResidentLayers);
     return NF_ERR_INVALID;
   }
+  const Tune tune = read_tune();
   Params p;
   p.wimg = wimg;
   p.io = io;
   p.first_mask_parity = first_mask_parity;
-  const size_t lds_bytes = (size_t)nlay * kLayerFloats * sizeof(float) + 64;
+  const size_t lds_bytes = (size_t)nlay * kLayerFloats * sizeof(float) + 128;
   const int cap = grid_cap > 0 && grid_cap < max_grid() ? grid_cap : max_grid();
-  // pick the tile count so that small batches still spread over the chip
-  int T = 4;
-  if (io.rows < (long long)cap * 8 * 128) T = 2;
-  if (io.rows < (long long)cap * 8 * 64) T = 1;
+  const int waves = tune.waves == 8 ? 8 : 16;
+  // tiles per wave: fewer for small batches so that they still spread over the chip
+  int T = waves == 8 ? (tune.T == 4 ? 4 : 2) : (tune.T == 1 ? 1 : 2);
+  while (T > 1 && io.rows < (long long)cap * waves * 32 * T) T >>= 1;
   const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
-  long long want = (groups + 7) / 8;
+  long long want = (groups + waves - 1) / waves;
   int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
-  switch (T) {
-    case 4: return launch_t<4>(p, grid, lds_bytes, stream);
-    case 2: return launch_t<2>(p, grid, lds_bytes, stream);
-    default: return launch_t<1>(p, grid, lds_bytes, stream);
-  }
+  if (waves == 16)
+    return T == 2 ? launch_dir<2, 16>(p, grid, lds_bytes, stream) : launch_dir<1, 16>(p, grid, lds_bytes, stream);
+  if (T == 4) return launch_dir<4, 8>(p, grid, lds_bytes, stream);
+  return T == 2 ? launch_dir<2, 8>(p, grid, lds_bytes, stream) : launch_dir<1, 8>(p, grid, lds_bytes, stream);
 }
 
 }  // namespace affine2d

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""A/B of affine2d_h64 kernel variants inside ONE process, interleaved rounds
+(cdna_hip_programming.md section 5.4 rule 24).  NF_AFFINE2D_TUNE = "T,WAVES"."""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from normalizing_flows_amd import _lib, flow  # noqa: E402
+from oracle import flows_np as O  # noqa: E402
+
+variants = sys.argv[1:] or ["2,16", "1,16", "4,8", "2,8"]
+rows = 1 << 20
+spec = O.make_affine_spec(8, final_std=0.02)
+cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
+f = flow.CouplingFlow(cfg, spec.layers)
+x = O.make_inputs("banana", rows)
+xd = flow.DeviceArray.from_numpy(x)
+lpd = flow.DeviceArray((rows,))
+ref = None
+times = {v: [] for v in variants}
+for rnd in range(7):
+    for v in variants:
+        os.environ["NF_AFFINE2D_TUNE"] = v
+        for i in range(3):
+            f.nll_enqueue(xd, rows, i, lpd)
+        f.synchronize()
+        f.timer_start()
+        for i in range(20):
+            f.nll_enqueue(xd, rows, i, lpd)
+        times[v].append(f.timer_stop() / 20)
+        if rnd == 0:
+            got = lpd.to_numpy()
+            if ref is None:
+                ref = got
+            assert (got == ref).all(), f"variant {v} changes the bits"
+for v in variants:
+    t = times[v]
+    med = statistics.median(t)
+    print(f"{v:12s} median {med*1e3:8.1f} us  min {min(t)*1e3:8.1f} us  evals/s {rows/med*1e3:.3e}  "
+          f"frac_of_157.3TF {rows*69632/med*1e3/1e12/157.3:.3f}")
