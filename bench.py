@@ -97,7 +97,7 @@ def main():
 
     dist = None
     comm = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("NF_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist  # gloo: CPU-side rendezvous only
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from normalizing_flows_amd import sharding

@@ -112,6 +112,11 @@ struct nf_flow {
   int device = 0;
   int path = PATH_GENERIC;
   hipStream_t stream = nullptr;
+  // the NLL tail (sum of block sums, RCCL all-reduce, 8-byte copy to the host) runs on a side
+  // stream so that the next batch's chain kernel does not wait behind a latency-bound collective
+  hipStream_t side = nullptr;
+  hipEvent_t ev_kernel[NF_NLL_SLOTS] = {}, ev_tail[NF_NLL_SLOTS] = {};
+  bool tail_pending[NF_NLL_SLOTS] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_weights = false;
   size_t weight_count = 0;
@@ -303,14 +308,21 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
     if (hipGetDevice(&f->device) != hipSuccess) { s = hip_fail(hipGetLastError(), "hipGetDevice", __FILE__, __LINE__); break; }
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&f->ev0)) != hipSuccess || (e = hipEventCreate(&f->ev1)) != hipSuccess ||
-        (e = hipMalloc(&f->d_block_sums, sizeof(double) * 4096)) != hipSuccess ||
+        (e = hipMalloc(&f->d_block_sums, sizeof(double) * 4096 * NF_NLL_SLOTS)) != hipSuccess ||
         (e = hipMalloc(&f->d_sum, sizeof(double) * NF_NLL_SLOTS)) != hipSuccess ||
         (e = hipHostMalloc(&f->h_ring, sizeof(double) * NF_NLL_SLOTS, hipHostMallocDefault)) != hipSuccess) {
       s = hip_fail(e, "flow resources", __FILE__, __LINE__);
       break;
     }
   } while (0);
+  for (int q = 0; s == NF_OK && q < NF_NLL_SLOTS; ++q) {
+    hipError_t e;
+    if ((e = hipEventCreateWithFlags(&f->ev_kernel[q], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&f->ev_tail[q], hipEventDisableTiming)) != hipSuccess)
+      s = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+  }
   if (s != NF_OK) { nf_flow_destroy(f); return s; }
   memset(f->ring_rows, 0, sizeof(f->ring_rows));
   *out_flow = f;
@@ -320,6 +332,12 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
 void nf_flow_destroy(nf_flow* f) {
   if (!f) return;
   if (f->stream) hipStreamSynchronize(f->stream);
+  if (f->side) hipStreamSynchronize(f->side);
+  for (int q = 0; q < NF_NLL_SLOTS; ++q) {
+    if (f->ev_kernel[q]) hipEventDestroy(f->ev_kernel[q]);
+    if (f->ev_tail[q]) hipEventDestroy(f->ev_tail[q]);
+  }
+  if (f->side) hipStreamDestroy(f->side);
   hipFree(f->d_wimg);
   f->plan.release();
   hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp);
@@ -382,6 +400,7 @@ int nf_flow_kernel_name(const nf_flow* f, char* buf, size_t buf_len) {
 int nf_flow_synchronize(nf_flow* f) {
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   NF_HIP(hipStreamSynchronize(f->stream));
+  NF_HIP(hipStreamSynchronize(f->side));
   return NF_OK;
 }
 
@@ -424,7 +443,7 @@ static int default_direction(const nf_flow* f) {
 }
 
 static int enqueue_log_prob(nf_flow* f, int direction, const float* x_dev, long long rows, float* lp_dev,
-                            bool want_sum, int* out_grid) {
+                            double* block_sums, int* out_grid) {
   ChainIO io;
   memset(&io, 0, sizeof(io));
   io.rows = rows;
@@ -433,7 +452,7 @@ static int enqueue_log_prob(nf_flow* f, int direction, const float* x_dev, long 
   direction_flags(direction, &io.descending, &io.inverse_op);
   io.x = x_dev;
   io.logprob_out = lp_dev;
-  io.block_sums = want_sum ? f->d_block_sums : nullptr;
+  io.block_sums = block_sums;
   io.add_base = 1;
   return run_chain_device(f, io, out_grid);
 }
@@ -452,12 +471,12 @@ int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, f
   if (rows == 0) return NF_OK;
   if (mem == NF_MEM_DEVICE) {
     NF_TRY(check_device_ptr(x, "x")); NF_TRY(check_device_ptr(out_log_prob, "out_log_prob"));
-    return enqueue_log_prob(f, direction, x, rows, out_log_prob, false, nullptr);
+    return enqueue_log_prob(f, direction, x, rows, out_log_prob, nullptr, nullptr);
   }
   NF_TRY(ensure_stage(f, rows));
   const int D = f->desc.event_dim;
   NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
-  NF_TRY(enqueue_log_prob(f, direction, f->d_x, rows, f->d_lp, false, nullptr));
+  NF_TRY(enqueue_log_prob(f, direction, f->d_x, rows, f->d_lp, nullptr, nullptr));
   NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows, hipMemcpyDeviceToHost, f->stream));
   NF_HIP(hipStreamSynchronize(f->stream));
   return NF_OK;
@@ -470,14 +489,22 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   if (rows_global < rows_local || rows_global < 1) { set_error("rows_global must be >= rows_local and >= 1"); return NF_ERR_INVALID; }
   NF_TRY(check_device_ptr(x_dev, "x")); NF_TRY(check_device_ptr(out_log_prob_dev, "out_log_prob"));
   int grid = 0;
+  double* sums = f->d_block_sums + (size_t)slot * 4096;
+  // the slot's previous tail must have read its block sums before this kernel rewrites them
+  if (f->tail_pending[slot]) NF_HIP(hipStreamWaitEvent(f->stream, f->ev_tail[slot], 0));
+  if (rows_local > 0)
+    NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, sums, &grid));
+  NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));
+  NF_HIP(hipStreamWaitEvent(f->side, f->ev_kernel[slot], 0));
   if (rows_local > 0) {
-    NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, true, &grid));
-    NF_TRY(launch_sum_blocks(f->d_block_sums, grid, f->d_sum + slot, f->stream));
+    NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->side));
   } else {
-    NF_HIP(hipMemsetAsync(f->d_sum + slot, 0, sizeof(double), f->stream));
+    NF_HIP(hipMemsetAsync(f->d_sum + slot, 0, sizeof(double), f->side));
   }
-  if (f->comm) NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_sum + slot, f->stream));
-  NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  if (f->comm) NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_sum + slot, f->side));
+  NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->side));
+  NF_HIP(hipEventRecord(f->ev_tail[slot], f->side));
+  f->tail_pending[slot] = true;
   f->ring_rows[slot] = rows_global;
   return NF_OK;
 }
@@ -497,7 +524,7 @@ int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, 
   if (!out_nll) { set_error("out_nll is NULL"); return NF_ERR_INVALID; }
   if (mem == NF_MEM_DEVICE) {
     NF_TRY(nf_nll_enqueue(f, x, rows_local, rows_global, out_log_prob, 0));
-    NF_HIP(hipStreamSynchronize(f->stream));
+    NF_TRY(nf_flow_synchronize(f));
     return nf_nll_result(f, 0, out_nll);
   }
   const int D = f->desc.event_dim;
@@ -508,7 +535,7 @@ int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, 
   NF_TRY(nf_nll_enqueue(f, f->d_x, rows_local, rows_global, out_log_prob ? f->d_lp : nullptr, 0));
   if (out_log_prob && rows_local > 0)
     NF_HIP(hipMemcpyAsync(out_log_prob, f->d_lp, sizeof(float) * rows_local, hipMemcpyDeviceToHost, f->stream));
-  NF_HIP(hipStreamSynchronize(f->stream));
+  NF_TRY(nf_flow_synchronize(f));
   return nf_nll_result(f, 0, out_nll);
 }
 

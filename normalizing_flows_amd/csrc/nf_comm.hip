@@ -5,6 +5,7 @@
 #include "nf_internal.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -32,10 +33,14 @@ Rccl g_rccl;
 
 int load_rccl() {
   if (g_rccl.lib) return NF_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // The ROCm installation's RCCL first, by path: a process that has also imported torch already
+  // holds torch's bundled librccl (same soname, built against another HIP runtime), and a bare
+  // soname would hand that copy back.  NF_RCCL_LIBRARY overrides.
+  const char* names[] = {getenv("NF_RCCL_LIBRARY"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
   void* lib = nullptr;
   for (const char* n : names) {
-    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!n || !*n) continue;
+    lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (lib) break;
   }
   if (!lib) {
