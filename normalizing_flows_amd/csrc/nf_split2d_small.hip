@@ -5,7 +5,9 @@
 // 12 FMA per sample per layer: there is no matrix work here.  One lane carries
 // two samples (one 16-byte load), the 4H+2 weights of a layer are wave-uniform
 // and come through the scalar cache (s_load), so the inner loop is pure VALU
-// with SGPR operands.  Bound: VALU issue / HBM (12 B per sample), see DESIGN.md.
+// with SGPR operands: per sample and layer 5 VALU per hidden unit + a
+// 6-instruction exp + 3.  Bound: VALU issue (HBM traffic is 12 B per sample),
+// see DESIGN.md.
 #include "nf_internal.h"
 
 #include <math.h>
@@ -14,45 +16,53 @@ namespace nf {
 namespace split2d {
 
 struct Params {
-  const float* wimg;  // [L][4H+2]
+  const float* wimg;  // [L][4H+2]: w0[H], b0[H], w1[H][2], b1[2]
   ChainIO io;
   int H;
-  int leaky;       // activation: 1 = leaky_relu(0.01), 0 = relu
   int first_flip;  // flip of layer 0
 };
 
-__device__ __forceinline__ float act_fn(float v, int leaky) {
-  return leaky ? (v >= 0.f ? v : 0.01f * v) : fmaxf(v, 0.f);
+__device__ __forceinline__ float exp_f32(float x) {
+  // 2^(x*log2 e) with the product carried in two floats (see nf_affine2d_h64.hip)
+  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float hi = x * kLog2eHi;
+  const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return fmaf(e, lo * kLn2, e);
 }
 
-// one sample through the layers this launch walks
-__device__ __forceinline__ void walk(const Params& p, float& v0, float& v1, float& ld) {
-  const ChainIO& io = p.io;
-  const int nlay = io.layer_end - io.layer_begin;
-  const int H = p.H;
-  for (int li = 0; li < nlay; ++li) {
-    const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
-    const int flip = (l & 1) ^ p.first_flip;
-    const float* __restrict__ w = p.wimg + (size_t)l * layer_floats(H);
-    const float c = flip ? v1 : v0;  // conditioning half (src/real_nvp.py:121-125)
-    float t = flip ? v0 : v1;
-    float shift = 0.f, ls = 0.f;
+// one coupling layer on two samples: c* condition, t* are transformed
+template <int LEAKY, int INV, int HT>
+__device__ __forceinline__ void layer(const float* __restrict__ w, int Hrt, float ca, float cb, float& ta, float& tb,
+                                      float& lda, float& ldb) {
+  const int H = HT > 0 ? HT : Hrt;
+  float sa = 0.f, la = 0.f, sb = 0.f, lb = 0.f;
 #pragma unroll 4
-    for (int k = 0; k < H; ++k) {
-      const float a = act_fn(fmaf(c, w[k], w[H + k]), p.leaky);
-      shift = fmaf(a, w[2 * H + 2 * k + 0], shift);
-      ls = fmaf(a, w[2 * H + 2 * k + 1], ls);
-    }
-    shift += w[4 * H + 0];
-    ls += w[4 * H + 1];
-    if (io.inverse_op) {
-      t = (t - shift) * expf(-ls);  // src/real_nvp.py:129
-      ld -= ls;                     // src/real_nvp.py:157
+  for (int k = 0; k < H; ++k) {
+    const float w0 = w[k], b0 = w[H + k], ws = w[2 * H + 2 * k], wl = w[2 * H + 2 * k + 1];
+    float a = fmaf(ca, w0, b0), b = fmaf(cb, w0, b0);
+    if (LEAKY) {  // jax.nn.leaky_relu, slope 0.01 < 1: max(v, 0.01 v)  (src/real_nvp.py:167)
+      a = fmaxf(a, 0.01f * a);
+      b = fmaxf(b, 0.01f * b);
     } else {
-      t = fmaf(t, expf(ls), shift);  // src/real_nvp.py:96
-      ld += ls;
+      a = fmaxf(a, 0.f);
+      b = fmaxf(b, 0.f);
     }
-    if (flip) v0 = t; else v1 = t;
+    sa = fmaf(a, ws, sa); la = fmaf(a, wl, la);
+    sb = fmaf(b, ws, sb); lb = fmaf(b, wl, lb);
+  }
+  const float bs = w[4 * H], bl = w[4 * H + 1];
+  sa += bs; la += bl; sb += bs; lb += bl;
+  if (INV) {
+    ta = (ta - sa) * exp_f32(-la);  // src/real_nvp.py:129
+    tb = (tb - sb) * exp_f32(-lb);
+    lda -= la;                      // src/real_nvp.py:157
+    ldb -= lb;
+  } else {
+    ta = fmaf(ta, exp_f32(la), sa);  // src/real_nvp.py:96
+    tb = fmaf(tb, exp_f32(lb), sb);
+    lda += la;
+    ldb += lb;
   }
 }
 
@@ -69,10 +79,14 @@ __device__ __forceinline__ float finish(const ChainIO& io, float v0, float v1, f
   return lp;
 }
 
+template <int LEAKY, int INV, int HT>
 __global__ __launch_bounds__(256) void chain_kernel(Params p) {
   const ChainIO& io = p.io;
   const long long rows = io.rows;
   const long long pairs = (rows + 1) / 2;
+  const int H = HT > 0 ? HT : p.H;
+  const int stride = layer_floats(H);
+  const int nlay = io.layer_end - io.layer_begin;
   double sum = 0.0;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < pairs;
        q += (long long)gridDim.x * 256) {
@@ -87,8 +101,22 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p) {
     }
     float lda = io.logdet_in ? io.logdet_in[r0] : 0.f;
     float ldb = (io.logdet_in && two) ? io.logdet_in[r0 + 1] : 0.f;
-    walk(p, v.x, v.y, lda);
-    walk(p, v.z, v.w, ldb);
+    // flips alternate, so layers are walked in pairs with fixed roles; an odd one first
+    int li = 0;
+    int l = io.descending ? io.layer_end - 1 : io.layer_begin;
+    const int step = io.descending ? -1 : 1;
+    if (((l & 1) ^ p.first_flip) != 0) {  // flipped layer: dim 1 conditions, dim 0 is transformed
+      layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.y, v.w, v.x, v.z, lda, ldb);
+      l += step;
+      ++li;
+    }
+    for (; li + 1 < nlay; li += 2) {
+      layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.x, v.z, v.y, v.w, lda, ldb);
+      layer<LEAKY, INV, HT>(p.wimg + (size_t)(l + step) * stride, H, v.y, v.w, v.x, v.z, lda, ldb);
+      l += 2 * step;
+    }
+    if (li < nlay) layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.x, v.z, v.y, v.w, lda, ldb);
+
     const float lpa = finish(io, v.x, v.y, lda);
     const float lpb = finish(io, v.z, v.w, ldb);
     if (two) {
@@ -113,7 +141,13 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p) {
   }
 }
 
-int max_grid() { return 2048; }
+int max_grid() { return 4096; }
+
+template <int LEAKY, int INV>
+static void launch_h(const Params& p, int grid, hipStream_t stream) {
+  if (p.H == 4) hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 4>), dim3(grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 0>), dim3(grid), dim3(256), 0, stream, p);
+}
 
 int launch(const float* wimg, int H, int activation, int first_flip, const ChainIO& io,
            hipStream_t stream, int* out_grid) {
@@ -125,13 +159,14 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
   p.wimg = wimg;
   p.io = io;
   p.H = H;
-  p.leaky = activation == NF_ACT_LEAKY_RELU;
   p.first_flip = first_flip & 1;
+  const bool leaky = activation == NF_ACT_LEAKY_RELU;
   const long long pairs = (io.rows + 1) / 2;
   long long want = (pairs + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > max_grid() ? max_grid() : want));
   if (out_grid) *out_grid = grid;
-  hipLaunchKernelGGL(chain_kernel, dim3(grid), dim3(256), 0, stream, p);
+  if (leaky) { if (io.inverse_op) launch_h<1, 1>(p, grid, stream); else launch_h<1, 0>(p, grid, stream); }
+  else { if (io.inverse_op) launch_h<0, 1>(p, grid, stream); else launch_h<0, 0>(p, grid, stream); }
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
