@@ -3,6 +3,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -26,12 +27,13 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorNoDevice ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
 }
 
-enum Path { PATH_AFFINE2D_H64 = 0, PATH_SPLIT2D_SMALL = 1, PATH_GENERIC = 2 };
+enum Path { PATH_AFFINE2D_H64 = 0, PATH_SPLIT2D_SMALL = 1, PATH_GENERIC = 2, PATH_RQS2D_H64 = 3 };
 
 static const char* path_name(int p) {
   switch (p) {
     case PATH_AFFINE2D_H64: return "affine2d_h64_mfma";
     case PATH_SPLIT2D_SMALL: return "split2d_small";
+    case PATH_RQS2D_H64: return "rqs2d_h64_mfma";
     default: return "generic_gemm";
   }
 }
@@ -165,6 +167,7 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
     return split2d::launch(f->d_wimg, f->desc.hidden[0], f->desc.activation,
                            f->desc.first_mask_parity, io, f->stream, out_grid);
   }
+  if (f->path == PATH_RQS2D_H64) return rqs2d::launch(f->d_wimg, f->desc, io, f->stream, out_grid);
   if (f->path == PATH_AFFINE2D_H64) {
     const int nlay = io.layer_end - io.layer_begin;
     if (nlay <= affine2d::kMaxResidentLayers)
@@ -301,6 +304,10 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
   else if (d.kind == NF_KIND_AFFINE_SPLIT && d.event_dim == 2 && d.num_hidden == 1 &&
            d.hidden[0] <= split2d::kMaxHidden)
     f->path = PATH_SPLIT2D_SMALL;
+  else if (d.kind == NF_KIND_RQS_MASKED && d.event_dim == 2 && d.num_hidden == 2 && d.hidden[0] == 64 &&
+           d.hidden[1] == 64 && d.activation == NF_ACT_RELU && rqs2d::supported_bins(d.rqs_bins) &&
+           getenv("NF_FORCE_GENERIC") == nullptr)
+    f->path = PATH_RQS2D_H64;
   else
     f->path = PATH_GENERIC;
   int s = NF_OK;
@@ -373,6 +380,19 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
       const float* b3 = W3 + 64 * 2;
       const int cond_dim = (d.first_mask_parity + l) & 1;
       affine2d::pack_layer(W1, b1, W2, b2, W3, b3, cond_dim, img.data() + (size_t)l * affine2d::kLayerFloats);
+    }
+  } else if (f->path == PATH_RQS2D_H64) {
+    const int P = 3 * d.rqs_bins + 1;
+    img.resize((size_t)d.num_layers * rqs2d::kLayerFloats);
+    for (int l = 0; l < d.num_layers; ++l) {
+      const float* W1 = packed + per_layer * l;
+      const float* b1 = W1 + 2 * 64;
+      const float* W2 = b1 + 64;
+      const float* b2 = W2 + 64 * 64;
+      const float* W3 = b2 + 64;
+      const float* b3 = W3 + 64 * 2 * P;
+      rqs2d::pack_layer(W1, b1, W2, b2, W3, b3, (d.first_mask_parity + l) & 1, d.rqs_bins,
+                        img.data() + (size_t)l * rqs2d::kLayerFloats);
     }
   } else if (f->path == PATH_SPLIT2D_SMALL) {
     // W0[1][H], b0[H], W1[H][2], b1[2] is already the kernel's order

@@ -69,6 +69,22 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
 int max_grid();  // blocks the launch uses at most (= size of block_sums needed)
 }  // namespace affine2d
 
+// ---- path 1b: masked RQS coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2*(3K+1) ----------
+namespace rqs2d {
+// image of ONE layer (floats); layers are streamed through an LDS double buffer
+constexpr int kA2 = 0;                 // [32 kstep][64 lane][2 mtile]   W2 (scaled 2^64)
+constexpr int kA3 = 4096;              // [32 kstep'][64 lane][2 mtile'] last Linear, k in accumulator order
+constexpr int kW1B1 = 8192;            // [64 k][2]
+constexpr int kB2 = kW1B1 + 128;       // [2 half][2 mtile][16 reg]
+constexpr int kB3 = kB2 + 64;          // [2 half][2 mtile'][16 reg']    bias of the parameters each half owns
+constexpr int kLayerFloats = kB3 + 64; // 8448 floats = 33,792 B
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, int K, float* image);
+int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStream_t stream, int* out_grid);
+int max_grid();
+bool supported_bins(int K);
+}  // namespace rqs2d
+
 // ---- path 2: split-halves affine coupling (variant A), D = 2, MLP 1 -> H -> 2 ----
 namespace split2d {
 constexpr int kMaxHidden = 64;

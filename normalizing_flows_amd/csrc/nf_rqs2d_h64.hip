@@ -1,0 +1,434 @@
+// Fused chain of masked rational-quadratic-spline coupling layers, event_dim = 2,
+// conditioner 2 -> 64 -> 64 -> 2*(3K+1) with relu (variant C of the reference:
+// src/maf_toy_densities.py:55-125; distrax.RationalQuadraticSpline semantics as
+// restated in SURVEY.md section 8a row c2: boundary_slopes='unconstrained',
+// min_bin_size, min_knot_slope, linear tails).
+//
+// Same skeleton as nf_affine2d_h64.hip (first Linear generated in the MFMA B-operand
+// layout, 64x64 Linear on v_mfma_f32_32x32x2_f32, accumulator = next operand), plus:
+//   * the last Linear (64 -> 3K+1 parameters of the ONE transformed dim; the masked dim's
+//     37 are never read by MaskedCoupling and are not computed) is a second MFMA pass whose
+//     B operand is relu(accumulator) taken register by register, with the k order of the
+//     weight image permuted to the accumulator's order -- no lane movement, no LDS;
+//   * the rows of that last Linear are assigned so that half-wave 0 receives the K width
+//     logits + K+1 slope logits and half-wave 1 the K height logits + K+1 slope logits of
+//     its sample: each half builds its own knots, the half that owns the search axis finds
+//     the bin, and three v_permlane32_swap carry (bin index, knot pair) across;
+//   * a layer's weight image is 33,792 B, so layers are streamed through a double buffer in
+//     LDS: the workgroup walks the chain layer by layer with one barrier per layer while the
+//     next layer's image is fetched (the flow state of every sample stays in registers).
+#include "nf_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace nf {
+namespace rqs2d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kReluShift = 64;  // see nf_affine2d_h64.hip
+
+static int param_of_slot(int half, int q, int K) {
+  // half 0: widths [0,K) then slopes; half 1: heights [K,2K) then slopes; -1 = unused row
+  if (q < K) return half == 0 ? q : K + q;
+  if (q < 2 * K + 1) return 2 * K + (q - K);
+  return -1;
+}
+
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, int K, float* img) {
+  const int P = 3 * K + 1;
+  const int dT = 1 - cond_dim;  // the transformed dim
+  memset(img, 0, sizeof(float) * kLayerFloats);
+  for (int s = 0; s < 32; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int m = 0; m < 2; ++m) {
+        const int k = 2 * s + (lane >> 5);
+        const int u = 32 * m + (lane & 31);
+        img[kA2 + (s * 64 + lane) * 2 + m] = ldexpf(W2[k * 64 + u], kReluShift);
+      }
+  // third pass: k-step s' = (m, r) of the accumulator, lane (u, hk): hidden unit j of that step
+  for (int m = 0; m < 2; ++m)
+    for (int r = 0; r < 16; ++r)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int hk = lane >> 5, u = lane & 31;
+        const int j = 32 * m + 8 * (r >> 2) + 4 * hk + (r & 3);
+        const int hD = (u >> 2) & 1, rr = (u & 3) + 4 * (u >> 3);
+        for (int mo = 0; mo < 2; ++mo) {
+          const int p = param_of_slot(hD, 16 * mo + rr, K);
+          img[kA3 + ((m * 16 + r) * 64 + lane) * 2 + mo] = p >= 0 ? W3[(size_t)j * (2 * P) + dT * P + p] : 0.f;
+        }
+      }
+  for (int k = 0; k < 64; ++k) {
+    img[kW1B1 + 2 * k + 0] = ldexpf(W1[cond_dim * 64 + k], -kReluShift);
+    img[kW1B1 + 2 * k + 1] = ldexpf(b1[k], -kReluShift);
+  }
+  for (int h = 0; h < 2; ++h)
+    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) {
+        img[kB2 + (h * 2 + m) * 16 + r] = b2[32 * m + 8 * (r >> 2) + 4 * h + (r & 3)];
+        const int p = param_of_slot(h, 16 * m + r, K);
+        img[kB3 + (h * 2 + m) * 16 + r] = p >= 0 ? b3[dT * P + p] : 0.f;
+      }
+}
+
+struct Params {
+  const float* wimg;
+  ChainIO io;
+  int first_mask_parity;
+  float range_min, range_max, min_bin, min_slope, slope_offset;
+};
+
+__device__ __forceinline__ float swap_halves(float v) {
+  // value of lane l^32
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ f32x16 lds_f32x16(const float* p) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 v;
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+  v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+  return v;
+}
+
+__device__ __forceinline__ float exp_f32(float x) {
+  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float hi = x * kLog2eHi;
+  const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return fmaf(e, lo * kLn2, e);
+}
+
+__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(exp_f32(-fabsf(v))); }
+
+// One spline evaluation.  lg[K]: this half's bin-size logits (widths on half 0, heights on
+// half 1); sg[K+1]: slope logits (both halves).  v: the value to transform (same in both
+// halves).  Returns the transformed value and log|det| (identical bits in both halves).
+template <int K, int INV>
+__device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K + 1], float v, int h,
+                                       const Params& p, float* out, float* logdet) {
+  const float total = p.range_max - p.range_min;
+  // softmax -> bin sizes -> knots on this half's axis
+  float mx = lg[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
+  float e[K];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { e[k] = exp_f32(lg[k] - mx); sum += e[k]; }
+  const float scale = (total - (float)K * p.min_bin) / sum;
+  float knot[K + 1];
+  knot[0] = p.range_min;
+#pragma unroll
+  for (int k = 0; k < K - 1; ++k) knot[k + 1] = knot[k] + fmaf(e[k], scale, p.min_bin);
+  knot[K] = p.range_max;
+  // bin: searched on the x axis (half 0) when going forward, on the y axis (half 1) inversely
+  int kb = 0;
+#pragma unroll
+  for (int k = 1; k < K; ++k) kb += (v >= knot[k]) ? 1 : 0;
+  const int kb_other = __float_as_int(swap_halves(__int_as_float(kb)));
+  kb = (h == INV) ? kb : kb_other;
+  float lo = knot[0], hi = knot[1], sl = sg[0], sr = sg[1];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool c = kb >= k;
+    lo = c ? knot[k] : lo;
+    hi = c ? knot[k + 1] : hi;
+    sl = c ? sg[k] : sl;
+    sr = c ? sg[k + 1] : sr;
+  }
+  const float lo_o = swap_halves(lo), hi_o = swap_halves(hi);
+  const float xl = h == 0 ? lo : lo_o, xr = h == 0 ? hi : hi_o;
+  const float yl = h == 0 ? lo_o : lo, yr = h == 0 ? hi_o : hi;
+  sl = softplus_f(sl + p.slope_offset) + p.min_slope;
+  sr = softplus_f(sr + p.slope_offset) + p.min_slope;
+  const float bw = xr - xl, bh = yr - yl;
+  const float delta = bh / bw;
+  const float st = sr + sl - 2.f * delta;
+  float res, ldv;
+  if (!INV) {
+    float z = (v - xl) / bw;
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float num = bh * (delta * zz + sl * z1mz);
+    const float den = delta + st * z1mz;
+    res = yl + num / den;
+    ldv = logf(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) / (den * den));
+  } else {
+    float u = (v - yl) / bh;
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    const float qc = -delta * u;
+    const float qb = sl - st * u;
+    const float qa = delta - qb;
+    float z = -2.f * qc / (qb + sqrtf(qb * qb - 4.f * qa * qc));
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    res = bw * z + xl;
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float den = delta + st * z1mz;
+    ldv = -logf(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) / (den * den));
+  }
+  // linear tails outside [range_min, range_max]: rare, so behind a wave-uniform test
+  const bool below = v <= p.range_min, above = v >= p.range_max;
+  if (__any(below || above)) {
+    const float s_first = softplus_f(sg[0] + p.slope_offset) + p.min_slope;
+    const float s_last = softplus_f(sg[K] + p.slope_offset) + p.min_slope;
+    if (!INV) {
+      if (below) { res = (v - p.range_min) * s_first + p.range_min; ldv = logf(s_first); }
+      if (above) { res = (v - p.range_max) * s_last + p.range_max; ldv = logf(s_last); }
+    } else {
+      if (below) { res = (v - p.range_min) / s_first + p.range_min; ldv = -logf(s_first); }
+      if (above) { res = (v - p.range_max) / s_last + p.range_max; ldv = -logf(s_last); }
+    }
+  }
+  *out = res;
+  *logdet = ldv;
+}
+
+template <int T, int WAVES, int INV, int K>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // two layer images
+  const ChainIO& io = p.io;
+  const int tid = threadIdx.x;
+  const int nlay = io.layer_end - io.layer_begin;
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int F4 = kLayerFloats / 4;               // float4s per image
+  constexpr int PER = (F4 + NTHREADS - 1) / NTHREADS;  // float4s per thread per image
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const long long rows = io.rows;
+  const long long groups = (rows + (T * 32 - 1)) / (T * 32);
+  const long long groups_per_pass = (long long)gridDim.x * WAVES;
+  const long long passes = (groups + groups_per_pass - 1) / groups_per_pass;  // same for every block
+  const float2* __restrict__ xin = reinterpret_cast<const float2*>(io.x);
+
+  auto layer_of = [&](int li) { return io.descending ? io.layer_end - 1 - li : io.layer_begin + li; };
+  // image staging: every thread carries PER (<= 5) float4 of the next layer's image in named
+  // registers while the current layer computes (reads are clamped, writes guarded)
+  static_assert(PER <= 5, "staging registers");
+  float4 st0, st1, st2, st3, st4;
+  st0 = st1 = st2 = st3 = st4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define NF_FETCH(li_)                                                                                  \
+  {                                                                                                   \
+    const float4* src_ = reinterpret_cast<const float4*>(p.wimg + (size_t)layer_of(li_) * kLayerFloats); \
+    st0 = src_[tid < F4 ? tid : F4 - 1];                                                               \
+    if (PER > 1) st1 = src_[tid + NTHREADS < F4 ? tid + NTHREADS : F4 - 1];                            \
+    if (PER > 2) st2 = src_[tid + 2 * NTHREADS < F4 ? tid + 2 * NTHREADS : F4 - 1];                    \
+    if (PER > 3) st3 = src_[tid + 3 * NTHREADS < F4 ? tid + 3 * NTHREADS : F4 - 1];                    \
+    if (PER > 4) st4 = src_[tid + 4 * NTHREADS < F4 ? tid + 4 * NTHREADS : F4 - 1];                    \
+  }
+#define NF_STASH(buf_)                                                                \
+  {                                                                                  \
+    float4* dst_ = reinterpret_cast<float4*>(lds + (buf_) * kLayerFloats);             \
+    if (tid < F4) dst_[tid] = st0;                                                   \
+    if (PER > 1 && tid + NTHREADS < F4) dst_[tid + NTHREADS] = st1;                  \
+    if (PER > 2 && tid + 2 * NTHREADS < F4) dst_[tid + 2 * NTHREADS] = st2;          \
+    if (PER > 3 && tid + 3 * NTHREADS < F4) dst_[tid + 3 * NTHREADS] = st3;          \
+    if (PER > 4 && tid + 4 * NTHREADS < F4) dst_[tid + 4 * NTHREADS] = st4;          \
+  }
+  NF_FETCH(0);
+  NF_STASH(0);
+  __syncthreads();
+
+  double wave_sum = 0.0;
+  long long step = 0;  // layers walked so far by this block: selects the LDS buffer
+  for (long long pass = 0; pass < passes; ++pass) {
+    const long long g = (pass * gridDim.x + blockIdx.x) * WAVES + wave;
+    const int c_first = (p.first_mask_parity + layer_of(0)) & 1;
+    float xc[T], xt[T], ld[T];
+    long long idx[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      idx[t] = g * (T * 32) + t * 32 + i;
+      float2 v = make_float2(0.f, 0.f);
+      if (idx[t] < rows) v = xin[idx[t]];
+      xc[t] = c_first ? v.y : v.x;
+      xt[t] = c_first ? v.x : v.y;
+      ld[t] = (io.logdet_in != nullptr && idx[t] < rows) ? io.logdet_in[idx[t]] : 0.f;
+    }
+
+    for (int li = 0; li < nlay; ++li, ++step) {
+      // request the image of the layer this block walks next (next pass wraps to its first)
+      const bool more = li + 1 < nlay || pass + 1 < passes;
+      if (more) NF_FETCH(li + 1 < nlay ? li + 1 : 0);
+
+      const float* L = lds + (step & 1) * kLayerFloats;
+      const float2* a2 = reinterpret_cast<const float2*>(L + kA2) + lane;
+      const float2* a3 = reinterpret_cast<const float2*>(L + kA3) + lane;
+      const float2* w1b1 = reinterpret_cast<const float2*>(L + kW1B1) + h;
+
+      f32x16 acc[T][2];
+      {
+        const f32x16 bias0 = lds_f32x16(L + kB2 + (h * 2 + 0) * 16);
+        const f32x16 bias1 = lds_f32x16(L + kB2 + (h * 2 + 1) * 16);
+        const float2 a = a2[0];
+        const float2 wb = w1b1[0];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float b = __builtin_amdgcn_fmed3f(fmaf(xc[t], wb.x, wb.y), 0.f, 1.f);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
+        }
+      }
+#pragma unroll 8
+      for (int s = 1; s < 32; ++s) {
+        const float2 a = a2[s * 64];
+        const float2 wb = w1b1[2 * s];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float b = __builtin_amdgcn_fmed3f(fmaf(xc[t], wb.x, wb.y), 0.f, 1.f);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[t][1], 0, 0, 0);
+        }
+      }
+
+      // last Linear: B operand = relu(accumulator register), k order = accumulator order
+      f32x16 out[T][2];
+      {
+        const f32x16 pb0 = lds_f32x16(L + kB3 + (h * 2 + 0) * 16);
+        const f32x16 pb1 = lds_f32x16(L + kB3 + (h * 2 + 1) * 16);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float2 a = a3[(m * 16 + r) * 64];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const float b = fmaxf(acc[t][m][r], 0.f);
+              if (m == 0 && r == 0) {
+                out[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, pb0, 0, 0, 0);
+                out[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, pb1, 0, 0, 0);
+              } else {
+                out[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, out[t][0], 0, 0, 0);
+                out[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, out[t][1], 0, 0, 0);
+              }
+            }
+          }
+      }
+
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float slot[32], lg[K], sg[K + 1];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { slot[q] = out[t][0][q]; slot[16 + q] = out[t][1][q]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) lg[k] = slot[k];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) sg[k] = slot[K + k];
+        float nt, l;
+        spline<K, INV>(lg, sg, xt[t], h, p, &nt, &l);
+        ld[t] += l;
+        xt[t] = xc[t];
+        xc[t] = nt;
+      }
+
+      if (more) NF_STASH((int)((step + 1) & 1));
+      __syncthreads();
+    }
+
+    const int c_last = (c_first + nlay) & 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float v0 = c_last ? xt[t] : xc[t];
+      const float v1 = c_last ? xc[t] : xt[t];
+      float lp = ld[t];
+      if (io.add_base) {
+        if (io.base == NF_BASE_STD_NORMAL) {
+          lp += -0.5f * (v0 * v0 + v1 * v1) - 1.8378770664093453f;
+        } else {
+          const bool inside = v0 >= 0.f && v0 <= 1.f && v1 >= 0.f && v1 <= 1.f;
+          if (!inside) lp = -INFINITY;
+        }
+      }
+      if (h == 0 && idx[t] < rows) {
+        if (io.y) reinterpret_cast<float2*>(io.y)[idx[t]] = make_float2(v0, v1);
+        if (io.logdet_out) io.logdet_out[idx[t]] = ld[t];
+        if (io.logprob_out) io.logprob_out[idx[t]] = lp;
+        wave_sum += (double)lp;
+      }
+    }
+  }
+
+  if (io.block_sums) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_down(wave_sum, off);
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);
+    if (lane == 0) red[wave] = wave_sum;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; ++w) s += red[w];
+      io.block_sums[blockIdx.x] = s;
+    }
+  }
+}
+
+#undef NF_FETCH
+#undef NF_STASH
+
+int max_grid() { return 256; }
+bool supported_bins(int K) { return K == 12 || K == 8 || K == 4; }
+
+template <int T, int WAVES, int INV, int K>
+static int launch_t(const Params& p, int grid, hipStream_t stream) {
+  const size_t lds_bytes = 2 * (size_t)kLayerFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((chain_kernel<T, WAVES, INV, K>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+template <int T, int WAVES, int K>
+static int launch_dir(const Params& p, int grid, hipStream_t stream) {
+  return p.io.inverse_op ? launch_t<T, WAVES, 1, K>(p, grid, stream) : launch_t<T, WAVES, 0, K>(p, grid, stream);
+}
+
+template <int K>
+static int launch_k(const Params& p, int grid, int T, int waves, hipStream_t stream) {
+  if (waves == 8) return T == 2 ? launch_dir<2, 8, K>(p, grid, stream) : launch_dir<1, 8, K>(p, grid, stream);
+  return launch_dir<1, 16, K>(p, grid, stream);
+}
+
+int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStream_t stream, int* out_grid) {
+  Params p;
+  p.wimg = wimg;
+  p.io = io;
+  p.first_mask_parity = d.first_mask_parity;
+  p.range_min = d.rqs_range_min;
+  p.range_max = d.rqs_range_max;
+  p.min_bin = d.rqs_min_bin_size;
+  p.min_slope = d.rqs_min_knot_slope;
+  p.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
+  int T = 1, waves = 16;  // NF_RQS2D_TUNE="T,WAVES": development knob
+  if (const char* e = getenv("NF_RQS2D_TUNE")) sscanf(e, "%d,%d", &T, &waves);
+  if (waves != 8) { waves = 16; T = 1; }
+  if (T != 2) T = 1;
+  const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
+  long long want = (groups + waves - 1) / waves;
+  const int grid = (int)(want < 1 ? 1 : (want > max_grid() ? max_grid() : want));
+  if (out_grid) *out_grid = grid;
+  switch (d.rqs_bins) {
+    case 12: return launch_k<12>(p, grid, T, waves, stream);
+    case 8: return launch_k<8>(p, grid, T, waves, stream);
+    case 4: return launch_k<4>(p, grid, T, waves, stream);
+    default: set_error("rqs2d kernel is built for 4, 8 and 12 bins"); return NF_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace rqs2d
+}  // namespace nf

@@ -478,3 +478,47 @@ def test_golden_vectors(nfa):
     assert_close(y, g["y"], "hand case y")
     assert_close(ld, g["logdet"], "hand case logdet")
     assert_close(f.log_prob(g["x"]), g["log_prob"], "hand case log_prob")
+
+
+# ------------------------------------------------------------------ fused spline kernel (D = 2, 64-wide)
+@pytest.mark.parametrize("K,L,parity,rows,lo,hi", [(12, 8, 1, 4096, -8.0, 8.0), (12, 1, 0, 33, -8.0, 8.0),
+                                                   (8, 3, 1, 1000, -5.0, 5.0), (4, 5, 0, 70001, -3.0, 4.0),
+                                                   (12, 11, 1, 513, -8.0, 8.0)])
+def test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi):
+    from normalizing_flows_amd import _lib
+    spec = O.make_rqs_spec(L, num_bins=K, range_min=lo, range_max=hi, final_std=0.05, first_parity=parity)
+    f = rqs_flow(nfa, spec, parity)
+    assert f.kernel_name == "rqs2d_h64_mfma"
+    x = O.make_inputs("banana", rows, seed=K * 100 + L)   # banana leaves [-8, 8]: tails are exercised
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, "fused rqs log_prob", 4 * e32)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    z32, ld32 = O.chain_forward(spec, x, np.float32)
+    assert_close(z, zr, "fused rqs z", 4 * np.abs(z32 - zr).max())
+    assert_close(ld, ldr, "fused rqs logdet", 4 * np.abs(ld32 - ldr).max())
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr2 = O.chain_inverse(spec, z)
+    x32, l32 = O.chain_inverse(spec, z, np.float32)
+    assert_close(xb, xr, "fused rqs inverse", 4 * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr2, "fused rqs inverse logdet", 4 * np.abs(l32 - ldr2).max())
+    assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
+    for l in range(min(L, 3)):
+        y, d = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, l, l + 1)
+        yr, dr = O.coupling_layer(spec, l, x, False)
+        assert_close(y, yr, f"fused rqs layer {l}", 1e-5)
+        assert_close(d, dr, f"fused rqs layer {l} logdet", 2e-5)
+
+
+def test_rqs_fused_identity_and_edges(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_rqs_spec(4, final_std=0.0, num_bins=4, range_min=-3.0, range_max=3.0)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "rqs2d_h64_mfma"
+    x = np.array([[-3.0, 3.0], [0.0, 0.0], [-5.0, 7.0], [2.999, -2.999], [1.2, -0.6], [3.0, -3.0]], np.float32)
+    y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    assert np.abs(y - x).max() <= 1e-5 and np.abs(ld).max() <= 1e-5
+    spec2 = O.make_rqs_spec(3, final_std=0.5, num_bins=8, range_min=-2.0, range_max=2.0, first_parity=0)
+    f2 = rqs_flow(nfa, spec2, 0)
+    assert_close(f2.log_prob(x), O.log_prob(spec2, x), "fused rqs edge inputs", 2e-5)
