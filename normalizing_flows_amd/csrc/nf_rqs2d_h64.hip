@@ -107,7 +107,17 @@ __device__ __forceinline__ float exp_f32(float x) {
   return fmaf(e, lo * kLn2, e);
 }
 
-__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(exp_f32(-fabsf(v))); }
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32, ~1 ulp each).  The
+// spline's intermediate quantities are O(1) and enter log_prob additively, so 1-2 ulp per
+// operation is far inside the float32 noise of the 8-layer chain (tests/test_parity_gpu.py).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+// softplus(v) = max(v, 0) + log(1 + exp(-|v|))
+__device__ __forceinline__ float softplus_f(float v) {
+  return fmaxf(v, 0.f) + fast_log(1.f + fast_exp(-fabsf(v)));
+}
 
 // One spline evaluation.  lg[K]: this half's bin-size logits (widths on half 0, heights on
 // half 1); sg[K+1]: slope logits (both halves).  v: the value to transform (same in both
@@ -122,9 +132,10 @@ __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K
   for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
   float e[K];
   float sum = 0.f;
+  const float mxl = -mx * 1.44269504f;
 #pragma unroll
-  for (int k = 0; k < K; ++k) { e[k] = exp_f32(lg[k] - mx); sum += e[k]; }
-  const float scale = (total - (float)K * p.min_bin) / sum;
+  for (int k = 0; k < K; ++k) { e[k] = __builtin_amdgcn_exp2f(fmaf(lg[k], 1.44269504f, mxl)); sum += e[k]; }
+  const float scale = fast_div(total - (float)K * p.min_bin, sum);
   float knot[K + 1];
   knot[0] = p.range_min;
 #pragma unroll
@@ -151,29 +162,32 @@ __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K
   sl = softplus_f(sl + p.slope_offset) + p.min_slope;
   sr = softplus_f(sr + p.slope_offset) + p.min_slope;
   const float bw = xr - xl, bh = yr - yl;
-  const float delta = bh / bw;
+  const float rbw = __builtin_amdgcn_rcpf(bw);
+  const float delta = bh * rbw;
   const float st = sr + sl - 2.f * delta;
   float res, ldv;
   if (!INV) {
-    float z = (v - xl) / bw;
+    float z = (v - xl) * rbw;
     z = fminf(fmaxf(z, 0.f), 1.f);
     const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
     const float num = bh * (delta * zz + sl * z1mz);
     const float den = delta + st * z1mz;
-    res = yl + num / den;
-    ldv = logf(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) / (den * den));
+    const float rden = __builtin_amdgcn_rcpf(den);
+    res = fmaf(num, rden, yl);
+    ldv = fast_log(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
   } else {
-    float u = (v - yl) / bh;
+    float u = fast_div(v - yl, bh);
     u = fminf(fmaxf(u, 0.f), 1.f);
     const float qc = -delta * u;
     const float qb = sl - st * u;
     const float qa = delta - qb;
-    float z = -2.f * qc / (qb + sqrtf(qb * qb - 4.f * qa * qc));
+    float z = fast_div(-2.f * qc, qb + __builtin_amdgcn_sqrtf(qb * qb - 4.f * qa * qc));
     z = fminf(fmaxf(z, 0.f), 1.f);
     res = bw * z + xl;
     const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
     const float den = delta + st * z1mz;
-    ldv = -logf(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) / (den * den));
+    const float rden = __builtin_amdgcn_rcpf(den);
+    ldv = -fast_log(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
   }
   // linear tails outside [range_min, range_max]: rare, so behind a wave-uniform test
   const bool below = v <= p.range_min, above = v >= p.range_max;
@@ -181,11 +195,11 @@ __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K
     const float s_first = softplus_f(sg[0] + p.slope_offset) + p.min_slope;
     const float s_last = softplus_f(sg[K] + p.slope_offset) + p.min_slope;
     if (!INV) {
-      if (below) { res = (v - p.range_min) * s_first + p.range_min; ldv = logf(s_first); }
-      if (above) { res = (v - p.range_max) * s_last + p.range_max; ldv = logf(s_last); }
+      if (below) { res = (v - p.range_min) * s_first + p.range_min; ldv = fast_log(s_first); }
+      if (above) { res = (v - p.range_max) * s_last + p.range_max; ldv = fast_log(s_last); }
     } else {
-      if (below) { res = (v - p.range_min) / s_first + p.range_min; ldv = -logf(s_first); }
-      if (above) { res = (v - p.range_max) / s_last + p.range_max; ldv = -logf(s_last); }
+      if (below) { res = fast_div(v - p.range_min, s_first) + p.range_min; ldv = -fast_log(s_first); }
+      if (above) { res = fast_div(v - p.range_max, s_last) + p.range_max; ldv = -fast_log(s_last); }
     }
   }
   *out = res;
@@ -420,7 +434,9 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   if (T != 2) T = 1;
   const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
   long long want = (groups + waves - 1) / waves;
-  const int grid = (int)(want < 1 ? 1 : (want > max_grid() ? max_grid() : want));
+  // 8-wave workgroups use 67.6 KB of LDS and <= 128 VGPRs: two of them share a CU
+  const int cap = waves == 8 ? 2 * max_grid() : max_grid();
+  const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
   switch (d.rqs_bins) {
     case 12: return launch_k<12>(p, grid, T, waves, stream);
