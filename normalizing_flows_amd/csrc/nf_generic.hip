@@ -16,6 +16,7 @@
 #include "nf_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -124,8 +125,120 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
     }
 }
 
+// ------------------------------------------------------------------------
+// Same product for the aligned case (lda, N, K multiples of 4, 16-byte aligned bases):
+// 128x128 block tile, BK = 32, float4 global loads, LDS double buffer with the next tile held
+// in registers while the current one computes (one barrier per k-tile), 2x2 waves of 64x64.
+// Blocks are renumbered so that each XCD's L2 sees a contiguous run of tiles.
+// ------------------------------------------------------------------------
+constexpr int FBM = 128, FBN = 128, FBK = 32;
+constexpr int kFastLdsFloats = 2 * (FBM * (FBK + 1) + FBK * FBN);
+
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kAs = FBM * (FBK + 1), kWs = FBK * FBN;  // buffer b: A at b*kAs, W at 2*kAs + b*kWs
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+  const int m0 = (id / gx) * FBM, n0 = (id % gx) * FBN;
+
+  // this thread's share of a k-tile: A rows ar + 32 e (e < 4), k quad akq; W rows wk + 8 e, col quad wc
+  const int ar = tid >> 3, akq = (tid & 7) * 4;
+  const int wk = tid >> 5, wc = (tid & 31) * 4;
+  float4 ra[4], rw[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gr = m0 + ar + 32 * e, gk = k0 + akq;
+      ra[e] = (gr < M && gk < K) ? *reinterpret_cast<const float4*>(A + (size_t)gr * lda + gk)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kk = k0 + wk + 8 * e, gc = n0 + wc;
+      rw[e] = (kk < K && gc < N) ? *reinterpret_cast<const float4*>(W + (size_t)kk * N + gc)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float* a = smem + b * kAs + (ar + 32 * e) * (FBK + 1) + akq;
+      a[0] = ra[e].x; a[1] = ra[e].y; a[2] = ra[e].z; a[3] = ra[e].w;
+      *reinterpret_cast<float4*>(smem + 2 * kAs + b * kWs + (wk + 8 * e) * FBN + wc) = rw[e];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (K + FBK - 1) / FBK;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int b = kt & 1;
+    if (kt + 1 < nk) fetch((kt + 1) * FBK);
+    const float* as = smem + b * kAs + (wm * 64 + i) * (FBK + 1) + h;
+    const float* ws = smem + 2 * kAs + b * kWs + h * FBN + wn * 64 + i;
+#pragma unroll
+    for (int s = 0; s < FBK / 2; ++s) {
+      const float a0 = as[2 * s], a1 = as[32 * (FBK + 1) + 2 * s];
+      const float b0 = ws[2 * s * FBN], b1 = ws[2 * s * FBN + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash(b ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + i;
+      if (col >= N) continue;
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (row >= M) continue;
+        float v = acc[t][u][r] + bv;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+        Cm[(size_t)row * ldc + col] = v;
+      }
+    }
+}
+
 static int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
                        int M, int N, int K, int act, hipStream_t stream) {
+  const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+  if (aligned && N >= 128 && K >= 32 && getenv("NF_GEMM_SIMPLE") == nullptr) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_set = true;
+    }
+    const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
+    hipLaunchKernelGGL(gemm_fast_kernel, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
+                       W, bias, Cm, ldc, M, N, K, act, gx, gy);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_bias_act_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, A, lda, W,
@@ -281,6 +394,161 @@ __global__ __launch_bounds__(256) void rqs_masked_kernel(float* __restrict__ y, 
   }
 }
 
+
+// Templated form (K bins known at compile time): one workgroup owns R whole rows, stages their
+// parameters through LDS with coalesced 16-byte loads (a lane's 3K+1 values are then a stride-(3K+1)
+// LDS read: odd stride, conflict-free), evaluates one (row, transformed dim) pair per thread and
+// iteration with everything in registers, and reduces each row's log-dets in a fixed order.
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+__device__ __forceinline__ float softplus_fast(float v) {
+  return fmaxf(v, 0.f) + flog(1.f + fexp2(-fabsf(v) * 1.44269504f));
+}
+
+template <int K, int INV>
+__device__ __forceinline__ void rqs_eval_reg(const float* __restrict__ p, const RqsConst& c, float v, float* out,
+                                             float* logdet) {
+  constexpr float kL2E = 1.44269504f;
+  const float total = c.range_max - c.range_min;
+  float lw[K], lh[K];
+  float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { lw[k] = p[k]; lh[k] = p[K + k]; mw = fmaxf(mw, lw[k]); mh = fmaxf(mh, lh[k]); }
+  float sw = 0.f, sh = 0.f;
+  const float mwl = -mw * kL2E, mhl = -mh * kL2E;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    lw[k] = fexp2(fmaf(lw[k], kL2E, mwl)); sw += lw[k];
+    lh[k] = fexp2(fmaf(lh[k], kL2E, mhl)); sh += lh[k];
+  }
+  const float scw = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sw);
+  const float sch = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sh);
+  // walk the knots, keep the bin that contains v on the search axis
+  float xl = c.range_min, yl = c.range_min;
+  float bxl = xl, byl = yl, bxr = 0.f, byr = 0.f, rsl = p[2 * K], rsr = p[2 * K + 1];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float xr = k == K - 1 ? c.range_max : xl + fmaf(lw[k], scw, c.min_bin);
+    const float yr = k == K - 1 ? c.range_max : yl + fmaf(lh[k], sch, c.min_bin);
+    if (k == 0) { bxr = xr; byr = yr; }
+    else {
+      const bool hit = v >= (INV ? yl : xl);   // the last bin whose left knot is <= v
+      bxl = hit ? xl : bxl; bxr = hit ? xr : bxr;
+      byl = hit ? yl : byl; byr = hit ? yr : byr;
+      rsl = hit ? p[2 * K + k] : rsl;
+      rsr = hit ? p[2 * K + k + 1] : rsr;
+    }
+    xl = xr; yl = yr;
+  }
+  const float sl = softplus_fast(rsl + c.slope_offset) + c.min_slope;
+  const float sr = softplus_fast(rsr + c.slope_offset) + c.min_slope;
+  const float bw = bxr - bxl, bh = byr - byl;
+  const float rbw = __builtin_amdgcn_rcpf(bw);
+  const float delta = bh * rbw;
+  const float st = sr + sl - 2.f * delta;
+  float res, ldv;
+  if (!INV) {
+    float z = (v - bxl) * rbw;
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
+    res = fmaf(bh * (delta * zz + sl * z1mz), rden, byl);
+    ldv = flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
+  } else {
+    float u = (v - byl) * __builtin_amdgcn_rcpf(bh);
+    u = fminf(fmaxf(u, 0.f), 1.f);
+    const float qc = -delta * u, qb = sl - st * u, qa = delta - qb;
+    float z = -2.f * qc * __builtin_amdgcn_rcpf(qb + __builtin_amdgcn_sqrtf(qb * qb - 4.f * qa * qc));
+    z = fminf(fmaxf(z, 0.f), 1.f);
+    res = fmaf(bw, z, bxl);
+    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
+    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
+    ldv = -flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
+  }
+  if (v <= c.range_min || v >= c.range_max) {  // linear tails
+    const bool below = v <= c.range_min;
+    const float edge = below ? c.range_min : c.range_max;
+    const float s = softplus_fast(p[below ? 2 * K : 3 * K] + c.slope_offset) + c.min_slope;
+    res = INV ? (v - edge) * __builtin_amdgcn_rcpf(s) + edge : (v - edge) * s + edge;
+    ldv = INV ? -flog(s) : flog(s);
+  }
+  *out = res;
+  *logdet = ldv;
+}
+
+template <int K, int INV>
+__global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, float* __restrict__ ld,
+                                                      const float* __restrict__ params, long long rows, int D,
+                                                      int pass_parity, int R, RqsConst c) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int P = 3 * K + 1;
+  const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
+  const int first_t = pass_parity == 0 ? 1 : 0;
+  const int tid = threadIdx.x;
+  const int tpr = 256 / R;  // threads per row
+  float* red = sm + (size_t)R * Dt * P;  // [256] partial log-dets
+  const long long nblk = (rows + R - 1) / R;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const long long row0 = blk * R;
+    const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
+    const int nfl = nrow * Dt * P;
+    const float* src = params + (size_t)row0 * Dt * P;
+    if (((size_t)row0 * Dt * P & 3) == 0) {
+      for (int q = tid * 4; q < nfl; q += 1024) {
+        if (q + 3 < nfl) *reinterpret_cast<float4*>(sm + q) = *reinterpret_cast<const float4*>(src + q);
+        else for (int e = q; e < nfl; ++e) sm[e] = src[e];
+      }
+    } else {
+      for (int q = tid; q < nfl; q += 256) sm[q] = src[q];
+    }
+    __syncthreads();
+    const int r = tid / tpr, sub = tid % tpr;
+    float acc = 0.f;
+    if (r < nrow) {
+      float* yr = y + (row0 + r) * D;
+      for (int dt = sub; dt < Dt; dt += tpr) {
+        const int d = first_t + 2 * dt;
+        float res, l;
+        rqs_eval_reg<K, INV>(sm + ((size_t)r * Dt + dt) * P, c, yr[d], &res, &l);
+        yr[d] = res;
+        acc += l;
+      }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = tpr >> 1; w > 0; w >>= 1) {  // fixed-order tree inside each row's thread group
+      if (sub < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (sub == 0 && r < nrow) ld[row0 + r] += red[tid];
+    __syncthreads();
+  }
+}
+
+template <int K>
+static bool launch_rqs_rows(float* y, float* ld, const float* params, long long rows, int D, int par, int inverse,
+                            const RqsConst& rc, hipStream_t stream) {
+  const int P = 3 * K + 1;
+  const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+  const size_t row_bytes = (size_t)Dt * P * sizeof(float);
+  if (row_bytes > 60 * 1024) return false;
+  int R = 1;
+  while (R < 256 && (size_t)(2 * R) * row_bytes <= 48 * 1024 && 256 / (2 * R) >= 1 && (2 * R) <= rows) R <<= 1;
+  const size_t lds = (size_t)R * row_bytes + 256 * sizeof(float);
+  const long long nblk = (rows + R - 1) / R;
+  const int grid = (int)std::min<long long>(nblk, 65536);
+  if (inverse) {
+    static bool a = false;
+    if (!a) { hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
+    hipLaunchKernelGGL((rqs_rows_kernel<K, 1>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
+  } else {
+    static bool a = false;
+    if (!a) { hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
+    hipLaunchKernelGGL((rqs_rows_kernel<K, 0>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
+  }
+  return true;
+}
+
 // log_prob = base log-density(z) + logdet; optional float64 block sums.
 __global__ __launch_bounds__(256) void base_log_prob_kernel(const float* __restrict__ z, const float* __restrict__ ld,
                                                            float* __restrict__ lp, double* __restrict__ block_sums,
@@ -362,6 +630,7 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   for (int j = 0; j < nlin; ++j) per_layer += (size_t)in[j] * out[j] + out[j];
 
   max_width = 0;
+  act_width = 0;
   std::vector<float> host;
   linears.assign((size_t)d.num_layers * nlin, Linear());
   for (int l = 0; l < d.num_layers; ++l) {
@@ -400,6 +669,8 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
         L.N = Nn;
       }
       max_width = std::max(max_width, L.N);
+      if (j < nlin - 1) act_width = std::max(act_width, L.N);
+      else param_width = std::max(param_width, L.N);
       L.w_off = host.size();
       host.insert(host.end(), w.begin(), w.end());
       while (host.size() % 4) host.push_back(0.f);
@@ -421,9 +692,11 @@ void Plan::release() {
 }
 
 int Plan::ensure_scratch(long long rows) {
-  // three buffers of max_width floats per row (two activation ping-pongs + parameters)
-  const size_t per_row = (size_t)3 * max_width * sizeof(float);
-  long long cap = (long long)((size_t)768 * 1024 * 1024 / per_row);
+  // per row: two activation ping-pong buffers + the conditioner's output; up to 4 GiB of the
+  // 288 GB so that even the 784-D flow walks 2^16 rows in one chunk (big M keeps the GEMMs of the
+  // narrow hidden layers at full occupancy)
+  const size_t per_row = ((size_t)2 * act_width + param_width) * sizeof(float);
+  long long cap = (long long)(((size_t)4 << 30) / per_row);
   cap = std::max<long long>(128, cap / 128 * 128);
   const long long want = std::min(rows, cap);
   if (want <= scratch_rows) return NF_OK;
@@ -452,8 +725,8 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
     const long long n = std::min(scratch_rows, io.rows - r0);
     float* yc = y + r0 * D;
     float* ldc = ld + r0;
-    float* buf[3] = {d_scratch, d_scratch + (size_t)scratch_rows * max_width,
-                     d_scratch + (size_t)2 * scratch_rows * max_width};
+    float* buf[3] = {d_scratch, d_scratch + (size_t)scratch_rows * act_width,
+                     d_scratch + (size_t)2 * scratch_rows * act_width};
     for (int li = 0; li < nlay; ++li) {
       const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
       const int par = (d.first_mask_parity + l) & 1;  // masked: pass-through parity; split: flip
@@ -479,6 +752,12 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         hipLaunchKernelGGL(affine_split_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
                            io.inverse_op);
       } else {
+        bool done = false;
+        if (getenv("NF_RQS_SIMPLE") == nullptr) {
+          if (rc.K == 8) done = launch_rqs_rows<8>(yc, ldc, params, n, D, par, io.inverse_op, rc, stream);
+          else if (rc.K == 12) done = launch_rqs_rows<12>(yc, ldc, params, n, D, par, io.inverse_op, rc, stream);
+        }
+        if (done) { NF_HIP(hipGetLastError()); continue; }
         const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
         int G = 1;
         while (G < 64 && G < Dt) G <<= 1;

@@ -108,6 +108,7 @@ struct Plan {
   float* d_scratch = nullptr;
   long long scratch_rows = 0;
   int max_width = 0;
+  int act_width = 0, param_width = 0;  // widest hidden layer / widest conditioner output
   int build(const nf_flow_desc& d, const float* packed);
   void release();
   int ensure_scratch(long long rows);

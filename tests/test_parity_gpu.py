@@ -522,3 +522,26 @@ def test_rqs_fused_identity_and_edges(nfa):
     spec2 = O.make_rqs_spec(3, final_std=0.5, num_bins=8, range_min=-2.0, range_max=2.0, first_parity=0)
     f2 = rqs_flow(nfa, spec2, 0)
     assert_close(f2.log_prob(x), O.log_prob(spec2, x), "fused rqs edge inputs", 2e-5)
+
+
+@pytest.mark.parametrize("K,D,hidden,L,rows", [(12, 2, (64, 64), 8, 4096), (8, 2, (64, 64), 3, 1000),
+                                               (8, 10, (32, 32), 2, 777), (12, 7, (40,), 3, 300)])
+def test_rqs_general_path_register_kernel(nfa, monkeypatch, K, D, hidden, L, rows):
+    """The general path's templated spline kernel (K = 8, 12), also on shapes the fused kernel takes
+    by default (forced off with NF_FORCE_GENERIC)."""
+    from normalizing_flows_amd import _lib
+    monkeypatch.setenv("NF_FORCE_GENERIC", "1")
+    spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=-6.0, range_max=6.0,
+                           final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "generic_gemm"
+    x = (np.random.default_rng(K + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, "general rqs log_prob", 4 * e32)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr = O.chain_inverse(spec, z)
+    x32, l32 = O.chain_inverse(spec, z, np.float32)
+    assert_close(xb, xr, "general rqs inverse", 4 * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr, "general rqs inverse logdet", 4 * np.abs(l32 - ldr).max())
