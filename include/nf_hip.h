@@ -159,6 +159,19 @@ int nf_chain_log_prob(nf_flow* flow, int direction, const float* x, int64_t rows
    Independent(Uniform(0,1)).log_prob (src/maf_mnist.py:84-88).  No handle needed. */
 int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, float* out, int mem);
 
+/* Base draw alone: Philox4x32-10 (counter = index of each group of four consecutive
+   elements of the row-major [rows, event_dim] matrix, key = seed), Box-Muller normals or
+   24-bit uniforms.  Replaces the base_distribution.sample / sample_N01 draw
+   (src/real_nvp_toy_densities.py:105-108,136; src/real_nvp.py:42-54); the reference's JAX
+   threefry stream itself is not reproduced. */
+int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* out, int mem);
+
+/* Replaces sample.apply -> distrax.Transformed.sample (src/real_nvp_toy_densities.py:126-136,
+   197-203; src/maf_toy_densities.py:128-139; src/maf_mnist.py:121-131) and sample_nvp_chain
+   (src/real_nvp.py:228-248): the base draw of nf_base_sample followed by the generative walk
+   of the chain, all on the device.  out_x[rows, event_dim]. */
+int nf_sample(nf_flow* flow, uint64_t seed, int64_t rows, float* out_x, int mem);
+
 /* Replaces Chain / MaskedCoupling forward_and_log_det, inverse_and_log_det and
    forward_nvp / inverse_nvp chains (see nf_direction).  Walks layers
    [layer_begin, layer_end) of the chain; pass 0, num_layers for the whole chain,

@@ -583,6 +583,56 @@ int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, floa
   return s;
 }
 
+int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* out, int mem) {
+  if (base != NF_BASE_STD_NORMAL && base != NF_BASE_UNIFORM01) { set_error("unknown base %d", base); return NF_ERR_INVALID; }
+  if (event_dim < 1 || rows < 0) { set_error("bad shape"); return NF_ERR_INVALID; }
+  if (rows == 0) return NF_OK;
+  if (!out) { set_error("out is NULL"); return NF_ERR_INVALID; }
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(generic::launch_base_sample(out, rows, event_dim, base, seed, nullptr));
+    return NF_OK;
+  }
+  float* d = nullptr;
+  NF_HIP(hipMalloc(&d, sizeof(float) * rows * event_dim));
+  int s = generic::launch_base_sample(d, rows, event_dim, base, seed, nullptr);
+  hipError_t e;
+  if (s == NF_OK && (e = hipMemcpy(out, d, sizeof(float) * rows * event_dim, hipMemcpyDeviceToHost)) != hipSuccess)
+    s = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+  hipFree(d);
+  return s;
+}
+
+int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
+  NF_TRY(check_ready(f, out_x, rows));
+  if (rows == 0) return NF_OK;
+  const int D = f->desc.event_dim;
+  // generative direction: Chain.inverse for the masked kinds (Transformed.sample), forward_nvp
+  // from layer 0 for the split kind (sample_nvp_chain)
+  const int direction = f->desc.kind == NF_KIND_AFFINE_SPLIT ? NF_DIR_FIRST_TO_LAST_FORWARD : NF_DIR_CHAIN_INVERSE;
+  ChainIO io;
+  memset(&io, 0, sizeof(io));
+  io.rows = rows;
+  io.layer_begin = 0;
+  io.layer_end = f->desc.num_layers;
+  direction_flags(direction, &io.descending, &io.inverse_op);
+  float* dst = out_x;
+  if (mem != NF_MEM_DEVICE) {
+    NF_TRY(ensure_stage(f, rows));
+    dst = f->d_x;
+  } else {
+    NF_TRY(check_device_ptr(out_x, "out_x"));
+  }
+  NF_TRY(generic::launch_base_sample(dst, rows, D, f->desc.base, seed, f->stream));
+  io.x = dst;
+  io.y = dst;  // every chain kernel may run in place
+  NF_TRY(run_chain_device(f, io, nullptr));
+  if (mem != NF_MEM_DEVICE) {
+    NF_HIP(hipMemcpyAsync(out_x, dst, sizeof(float) * rows * D, hipMemcpyDeviceToHost, f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
+  }
+  return NF_OK;
+}
+
 int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev) {
   if (!x_dev || !out_dev || rows < 1) { set_error("bad argument"); return NF_ERR_INVALID; }
   NF_TRY(generic::launch_debug_read_f2(x_dev, rows, out_dev, nullptr));

@@ -590,6 +590,68 @@ int launch_base_log_prob(const float* z, const float* ld, float* lp, double* blo
   return NF_OK;
 }
 
+// ------------------------------------------------------------------------
+// Base sampler: Philox4x32-10, counter = index of a group of 4
+// consecutive elements of the row-major [rows, D] matrix, key = the 64-bit seed.  Normals by
+// Box-Muller on uniform pairs (u0,u1) -> (n0,n1), (u2,u3) -> (n2,n3); uniforms are 24-bit.
+// The reference draws with JAX threefry (src/real_nvp_toy_densities.py:136,
+// src/real_nvp.py:52-54); bit parity with it is out of scope, the oracle restates THIS
+// generator (oracle/flows_np.py philox_*).
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void base_sample_kernel(float* __restrict__ out, long long total, int base,
+                                                         unsigned long long seed) {
+  const long long groups = (total + 3) / 4;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)g, (unsigned)(g >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+    float v[4];
+    if (base == NF_BASE_UNIFORM01) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)(r[e] >> 8) * 5.9604644775390625e-08f;  // [0, 1)
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const float u0 = ((float)(r[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1)
+        const float u1 = ((float)(r[e + 1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+        const float rad = sqrtf(-2.f * logf(u0));
+        float sn, cs;
+        sincospif(2.f * u1, &sn, &cs);
+        v[e] = rad * cs;
+        v[e + 1] = rad * sn;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * g + e < total) out[4 * g + e] = v[e];
+  }
+}
+
+int launch_base_sample(float* out, long long rows, int D, int base, unsigned long long seed, hipStream_t stream) {
+  const long long total = rows * D;
+  const long long groups = (total + 3) / 4;
+  const int grid = (int)std::min<long long>(4096, (groups + 255) / 256);
+  hipLaunchKernelGGL(base_sample_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, stream, out, total, base, seed);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // Streaming read of a [rows, 2] float32 matrix with the hot path's access shape (one float2
 // per lane); exists to calibrate rocprofv3's FETCH_SIZE on a known byte count
 // (MI355X_MICROARCH.md, HBM section: widths other than 16 B/lane are uncalibrated).

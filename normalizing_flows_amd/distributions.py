@@ -3,9 +3,8 @@
 `Transformed(Independent(Normal(0,1)), Inverse(Chain(layers)))`
 (src/real_nvp_toy_densities.py:104-110) and the Uniform(0,1) base of the MNIST
 flow (src/maf_mnist.py:84-89).  `Transformed.log_prob` is ONE fused launch of
-libnf_hip (chain walk + base log-density); base draws for `sample` come from a
-host Philox generator (on-device sampling is a "next" row) and the
-chain is then walked on the GPU.
+libnf_hip (chain walk + base log-density); `sample` draws the base on the GPU
+(Philox4x32-10) and walks the chain in the same call.
 """
 from __future__ import annotations
 
@@ -28,11 +27,26 @@ def _as_shape(sample_shape: IntLike) -> Tuple[int, ...]:
     return tuple(int(s) for s in sample_shape)
 
 
-def _rng(seed) -> np.random.Generator:
-    if isinstance(seed, np.random.Generator):
-        return seed
-    seed = np.asarray(seed).astype(np.uint64).ravel()
-    return np.random.Generator(np.random.Philox(key=int(seed[-1]) if seed.size else 0))
+def _seed_u64(seed) -> int:
+    """An int, or a key array as the reference passes (`next(prng_seq)`): its words folded to 64 bits."""
+    words = np.asarray(seed).astype(np.uint64).ravel()
+    out = 0
+    for w in words:
+        out = (out * 0x9E3779B97F4A7C15 + int(w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def _device_base_sample(base: int, event_shape: Tuple[int, ...], seed, sample_shape: IntLike) -> np.ndarray:
+    """Philox4x32-10 draw on the GPU (nf_base_sample): [*sample_shape, *event_shape] float32."""
+    shape = _as_shape(sample_shape)
+    rows = int(np.prod(shape)) if shape else 1
+    D = int(np.prod(event_shape)) if event_shape else 1
+    lib = _lib.load()
+    _lib.require_device()
+    out = np.empty((rows, D), np.float32)
+    check(lib.nf_base_sample(base, D, C.c_uint64(_seed_u64(seed)), rows, out.ctypes.data_as(C.c_void_p),
+                             _lib.MEM_HOST))
+    return out.reshape(shape + tuple(event_shape))
 
 
 def _device_base_log_prob(base: int, event_shape: Tuple[int, ...], value):
@@ -78,8 +92,9 @@ class Normal(Distribution):
         return bool(np.all(self.loc == 0) and np.all(self.scale == 1))
 
     def sample(self, *, seed, sample_shape: IntLike = ()):
-        shape = _as_shape(sample_shape) + tuple(self.batch_shape)
-        return (_rng(seed).standard_normal(shape) * self.scale + self.loc).astype(np.float32)
+        if not self.is_standard():
+            raise NotImplementedError("only Normal(0, 1) draws have a kernel (no CPU fallback)")
+        return _device_base_sample(_lib.BASE_STD_NORMAL, tuple(self.batch_shape), seed, sample_shape)
 
     def log_prob(self, value):
         raise NotImplementedError("element-wise Normal.log_prob is off the accelerated path; wrap it in "
@@ -99,8 +114,9 @@ class Uniform(Distribution):
         return bool(np.all(self.low == 0) and np.all(self.high == 1))
 
     def sample(self, *, seed, sample_shape: IntLike = ()):
-        shape = _as_shape(sample_shape) + tuple(self.batch_shape)
-        return (_rng(seed).random(shape) * (self.high - self.low) + self.low).astype(np.float32)
+        if not self.is_standard():
+            raise NotImplementedError("only Uniform(0, 1) draws have a kernel (no CPU fallback)")
+        return _device_base_sample(_lib.BASE_UNIFORM01, tuple(self.batch_shape), seed, sample_shape)
 
     def log_prob(self, value):
         raise NotImplementedError("element-wise Uniform.log_prob is off the accelerated path; wrap it in "
@@ -160,8 +176,9 @@ class MultivariateNormalDiag(Distribution):
         return None
 
     def sample(self, *, seed, sample_shape: IntLike = ()):
-        shape = _as_shape(sample_shape) + tuple(self.event_shape)
-        return (_rng(seed).standard_normal(shape) * self.scale_diag + self.loc).astype(np.float32)
+        if self._base_code() is None:
+            raise NotImplementedError("only MultivariateNormalDiag(0, I) draws have a kernel")
+        return _device_base_sample(_lib.BASE_STD_NORMAL, tuple(self.event_shape), seed, sample_shape)
 
     def log_prob(self, value):
         code = self._base_code()
@@ -218,9 +235,18 @@ class Transformed(Distribution):
         return flow.nll(rows)
 
     def sample(self, *, seed, sample_shape: IntLike = ()):
-        """Base draw on the host (Philox), bijector.forward on the GPU."""
-        z = self.distribution.sample(seed=seed, sample_shape=sample_shape)
-        return self.bijector.forward(z)
+        """Base draw (Philox4x32-10) and bijector.forward in one device call (nf_sample); identical
+        to `bijector.forward(distribution.sample(seed=seed, sample_shape=sample_shape))`."""
+        flow, direction = self._lowered()
+        if direction != _lib.DIR_CHAIN_FORWARD:
+            return self.bijector.forward(self.distribution.sample(seed=seed, sample_shape=sample_shape))
+        shape = _as_shape(sample_shape)
+        rows = int(np.prod(shape)) if shape else 1
+        D = int(np.prod(self.event_shape))
+        out = np.empty((rows, D), np.float32)
+        check(_lib.load().nf_sample(flow._h, C.c_uint64(_seed_u64(seed)), rows, out.ctypes.data_as(C.c_void_p),
+                                    _lib.MEM_HOST))
+        return out.reshape(shape + self.event_shape)
 
     def sample_and_log_prob(self, *, seed, sample_shape: IntLike = ()):
         x = self.sample(seed=seed, sample_shape=sample_shape)

@@ -21,7 +21,7 @@ _N01 = MultivariateNormalDiag(loc=np.zeros(2, np.float32), scale_diag=np.ones(2,
 
 
 def sample_N01(N: int, seed) -> np.ndarray:
-    """src/real_nvp.py:42-54 (host Philox draw instead of JAX threefry)."""
+    """src/real_nvp.py:42-54 (Philox4x32-10 on the GPU instead of JAX threefry)."""
     return _N01.sample(seed=seed, sample_shape=(N,))
 
 

@@ -491,3 +491,49 @@ def make_inputs(density: str, n: int, seed: int = 2123) -> np.ndarray:
     else:
         raise ValueError(density)
     return rows.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# base sampler: restatement of libnf_hip's Philox4x32-10 draw (include/nf_hip.h nf_base_sample).
+# The reference draws with JAX threefry; that stream is not reproduced.
+# --------------------------------------------------------------------------
+def philox4x32_10(counter_lo, counter_hi, seed):
+    """Vectorised Philox4x32-10: counters (c0=counter_lo, c1=counter_hi, 0, 0), key = seed (64 bit)."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    c0 = np.asarray(counter_lo, np.uint64) & mask
+    c1 = np.asarray(counter_hi, np.uint64) & mask
+    c2 = np.zeros_like(c0)
+    c3 = np.zeros_like(c0)
+    k0 = np.uint64(seed & 0xFFFFFFFF)
+    k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c0, c1, c2, c3
+
+
+def base_sample(base: str, rows: int, event_size: int, seed: int) -> np.ndarray:
+    """float64 restatement of nf_base_sample: [rows, event_size]."""
+    total = rows * event_size
+    groups = (total + 3) // 4
+    g = np.arange(groups, dtype=np.uint64)
+    r = np.stack(philox4x32_10(g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), int(seed)), axis=-1)  # [groups, 4]
+    m = (r >> np.uint64(8)).astype(np.float64)
+    if base == "uniform01":
+        v = m * 2.0 ** -24
+    else:
+        u = (m + 0.5) * 2.0 ** -24
+        rad = np.sqrt(-2.0 * np.log(u[:, 0::2]))
+        ang = 2.0 * np.pi * u[:, 1::2]
+        v = np.empty_like(u)
+        v[:, 0::2] = rad * np.cos(ang)
+        v[:, 1::2] = rad * np.sin(ang)
+    return v.reshape(-1)[:total].reshape(rows, event_size)

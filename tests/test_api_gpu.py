@@ -84,8 +84,13 @@ def test_real_nvp_toy_script(distrax):
     # sample.apply: base draw on the host, Chain.inverse on the GPU
     s = model.sample(seed=7, sample_shape=(1000,))
     z = model.distribution.sample(seed=7, sample_shape=(1000,))
-    assert s.shape == (1000, 2)
-    assert (np.abs(s - O.sample_from_z(spec, z)) <= tol(O.sample_from_z(spec, z))).all()
+    zr = O.base_sample("normal", 1000, 2, 7)              # the oracle's restatement of the Philox draw
+    assert s.shape == (1000, 2) and z.shape == (1000, 2)
+    assert np.abs(z - zr).max() <= 2e-6
+    assert (np.abs(s - O.sample_from_z(spec, zr)) <= 2 * tol(O.sample_from_z(spec, zr))).all()
+    assert np.array_equal(s, model.bijector.forward(z))   # one device call == draw, then walk
+    big = model.sample(seed=np.array([3, 4], np.uint32), sample_shape=(1 << 20,))   # N = 10^6 in the reference
+    assert big.shape == (1 << 20, 2) and np.isfinite(big).all() and abs(big.mean()) < 5
     # bijector protocol on the pieces
     chain = model.bijector.bijector
     y, ld = chain.forward_and_log_det(x)
@@ -171,10 +176,10 @@ def test_maf_toy_script(distrax):
     assert (np.abs(lp - ref) <= np.maximum(tol(ref), 4 * e32)).all()
     assert abs(model.nll(x) - O.nll(spec, x)) <= 1e-5 * max(1.0, abs(O.nll(spec, x)))
     s = model.sample(seed=11, sample_shape=500)
-    z = model.distribution.sample(seed=11, sample_shape=500)
+    z = O.base_sample("normal", 500, 2, 11)
     sr = O.sample_from_z(spec, z)
-    e32 = np.abs(O.sample_from_z(spec, z, np.float32) - sr).max()
-    assert (np.abs(s - sr) <= np.maximum(tol(sr), 4 * e32)).all()
+    e32 = np.abs(O.sample_from_z(spec, z.astype(np.float32), np.float32) - sr).max()
+    assert (np.abs(s - sr) <= np.maximum(2 * tol(sr), 4 * e32)).all()
 
 
 def test_maf_mnist_script_shapes(distrax):
@@ -205,6 +210,7 @@ def test_real_nvp_py_free_functions(distrax):
     assert abs(R.loss(params, fns_config, y) - O.a_nll(params, flips, y)) <= 1e-5
     x = R.sample_nvp_chain(params, fns_config, R.sample_N01, 1000, 7809)
     z = R.sample_N01(1000, 7809)
+    assert np.abs(z - O.base_sample("normal", 1000, 2, 7809)).max() <= 2e-6
     xr = O.a_sample_chain_from_z(params, flips, z)
     assert (np.abs(x - xr) <= tol(xr)).all()
     # single-layer functions
@@ -222,3 +228,16 @@ def test_real_nvp_py_free_functions(distrax):
     assert (np.abs(lp1 - ref1) <= tol(ref1)).all()
     with pytest.raises(NotImplementedError):
         R.log_prob_nvp_chains(params, fns_config, lambda v: v.sum(-1), y)
+
+
+def test_mnist_shape_sampling(distrax):
+    """Transformed.sample on the 784-D flow: Uniform base draw + spline inverse walk on the GPU."""
+    rng = np.random.default_rng(9)
+    model, layers = make_flow_model_rqs(distrax, (28, 28, 1), 2, [512, 512, 512], 8, 0.0, 1.0, "uniform", rng, 0.1)
+    spec = spec_of(layers, "rqs", 784, num_bins=8, range_min=0.0, range_max=1.0, base="uniform01")
+    s = model.sample(seed=21, sample_shape=(48,))
+    assert s.shape == (48, 28, 28, 1)
+    z = O.base_sample("uniform01", 48, 784, 21)
+    sr = O.sample_from_z(spec, z)
+    e32 = np.abs(O.sample_from_z(spec, z.astype(np.float32), np.float32) - sr).max()
+    assert (np.abs(s.reshape(48, 784) - sr) <= np.maximum(tol(sr), 4 * e32)).all()
