@@ -32,6 +32,21 @@ FLOP_PER_EVAL_L8 = 69632       # L * 2 * (2*64 + 64*64 + 64*2), 
 BYTES_PER_EVAL = 12            # 8 B in (x[2] f32) + 4 B out (log_prob f32)
 
 
+def profiled_traffic(kernel_prefix="void nf::affine2d::chain_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
+    command (profiles/collect_r01.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
+    MI355X_MICROARCH.md prescribes and profiles/calibrate_fetch.py confirms).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "final_bench_n1_pmc_summary.json")
+    try:
+        summary = json.load(open(path))
+        for name, counters in summary.items():
+            if name.startswith(kernel_prefix) and counters.get("hbm_bytes_per_launch"):
+                return float(counters["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def usable_cpus():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -162,7 +177,9 @@ def main():
             "nll": nll,
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": profiled_traffic() if (rows == 1 << 20 and args.layers == 8) else None,
+                         "traffic_unit": "bytes of HBM per launch (rocprofv3 PMC, profiles/r01); algorithmic "
+                                         f"{rows * BYTES_PER_EVAL}",
                          "hbm_algorithmic_GBps": rows * BYTES_PER_EVAL / kern_s / 1e9,
                          "kernel_ms": kern_s * 1e3},
         }
