@@ -172,6 +172,16 @@ int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* 
    of the chain, all on the device.  out_x[rows, event_dim]. */
 int nf_sample(nf_flow* flow, uint64_t seed, int64_t rows, float* out_x, int mem);
 
+/* Synthetic 2-D training/evaluation rows with the distributions of the reference's host-side
+   generators: make_dataset_banana (src/densities/banana.py:31-41), make_dataset_energy_1..4
+   (src/densities/energies.py:47-127), make_dataset_gaussian_blobs
+   (src/densities/gaussian_blobs.py:34-59).  out[rows, 2]; Philox4x32-10 keyed by seed. */
+typedef enum nf_density {
+  NF_DENSITY_BANANA = 0, NF_DENSITY_ENERGY1 = 1, NF_DENSITY_ENERGY2 = 2, NF_DENSITY_ENERGY3 = 3,
+  NF_DENSITY_ENERGY4 = 4, NF_DENSITY_BLOBS = 5
+} nf_density;
+int nf_density_sample(int density, uint64_t seed, int64_t rows, float* out, int mem);
+
 /* Replaces Chain / MaskedCoupling forward_and_log_det, inverse_and_log_det and
    forward_nvp / inverse_nvp chains (see nf_direction).  Walks layers
    [layer_begin, layer_end) of the chain; pass 0, num_layers for the whole chain,

@@ -10,7 +10,8 @@ does.
 """
 from ._lib import NFError
 from .bijectors import Bijector, Chain, Inverse, MaskedCoupling, RationalQuadraticSpline, ScalarAffine
-from .conditioner import MLPConditioner, layers_from_haiku_params, make_conditioner
+from .conditioner import (MLPConditioner, layers_from_haiku_params, layers_to_haiku_params, load_params,
+                          make_conditioner, save_params)
 from .distributions import (Distribution, Independent, MultivariateNormalDiag, Normal, Transformed,
                             Uniform)
 from .flow import CouplingFlow, DeviceArray, FlowConfig
@@ -18,7 +19,8 @@ from .sharding import RcclComm, ShardedNLL, shard_rows
 
 __all__ = [
     "NFError", "Bijector", "Chain", "Inverse", "MaskedCoupling", "RationalQuadraticSpline", "ScalarAffine",
-    "MLPConditioner", "layers_from_haiku_params", "make_conditioner", "Distribution", "Independent",
+    "MLPConditioner", "layers_from_haiku_params", "layers_to_haiku_params", "load_params", "save_params",
+    "make_conditioner", "Distribution", "Independent",
     "MultivariateNormalDiag", "Normal", "Transformed", "Uniform", "CouplingFlow", "DeviceArray",
     "FlowConfig", "RcclComm", "ShardedNLL", "shard_rows",
 ]

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "nf_chain_log_prob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_base_log_prob": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_base_sample": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),
+    "nf_density_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),
     "nf_sample": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),
     "nf_chain_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int]),

@@ -149,3 +149,39 @@ def layers_from_haiku_params(params: Mapping[str, Mapping[str, np.ndarray]]) -> 
             raise ValueError(f"coupling layer {k}: MLP linears are not consecutive")
         out.append([hidden[k][i] for i in idx] + [final[k]])
     return out
+
+
+def layers_to_haiku_params(layers: Sequence[Sequence[LinearParams]]) -> Dict[str, Dict[str, np.ndarray]]:
+    """Inverse of `layers_from_haiku_params`: per-layer Linear lists -> haiku-named dict."""
+    out: Dict[str, Dict[str, np.ndarray]] = {}
+    for k, layer in enumerate(layers):
+        sfx = "" if k == 0 else f"_{k}"
+        for i, (W, b) in enumerate(layer[:-1]):
+            out[f"mlp{sfx}/~/linear_{i}"] = {"w": np.asarray(W, np.float32), "b": np.asarray(b, np.float32)}
+        W, b = layer[-1]
+        out[f"linear{sfx}"] = {"w": np.asarray(W, np.float32), "b": np.asarray(b, np.float32)}
+    return out
+
+
+def save_params(path: str, params: Mapping[str, Mapping[str, np.ndarray]]) -> None:
+    """Weight file (the reference keeps parameters in process memory only):
+    one .npz whose keys are '<haiku module name>/w' and '<haiku module name>/b', float32."""
+    flat = {}
+    for name, mod in params.items():
+        flat[f"{name}/w"] = np.asarray(mod["w"], np.float32)
+        flat[f"{name}/b"] = np.asarray(mod["b"], np.float32)
+    np.savez(path, **flat)
+
+
+def load_params(path: str) -> Dict[str, Dict[str, np.ndarray]]:
+    out: Dict[str, Dict[str, np.ndarray]] = {}
+    with np.load(path) as f:
+        for key in f.files:
+            name, leaf = key.rsplit("/", 1)
+            if leaf not in ("w", "b"):
+                raise ValueError(f"unexpected entry {key!r} in weight file")
+            out.setdefault(name, {})[leaf] = f[key]
+    for name, mod in out.items():
+        if set(mod) != {"w", "b"}:
+            raise ValueError(f"module {name!r} lacks w or b")
+    return out

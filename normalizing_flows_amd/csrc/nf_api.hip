@@ -602,6 +602,25 @@ int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* 
   return s;
 }
 
+int nf_density_sample(int density, uint64_t seed, int64_t rows, float* out, int mem) {
+  if (density < NF_DENSITY_BANANA || density > NF_DENSITY_BLOBS) { set_error("unknown density %d", density); return NF_ERR_INVALID; }
+  if (rows < 0) { set_error("rows must be >= 0"); return NF_ERR_INVALID; }
+  if (rows == 0) return NF_OK;
+  if (!out) { set_error("out is NULL"); return NF_ERR_INVALID; }
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(check_device_ptr(out, "out"));
+    return generic::launch_density_sample(out, rows, density, seed, nullptr);
+  }
+  float* d = nullptr;
+  NF_HIP(hipMalloc(&d, sizeof(float) * rows * 2));
+  int s = generic::launch_density_sample(d, rows, density, seed, nullptr);
+  hipError_t e;
+  if (s == NF_OK && (e = hipMemcpy(out, d, sizeof(float) * rows * 2, hipMemcpyDeviceToHost)) != hipSuccess)
+    s = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+  hipFree(d);
+  return s;
+}
+
 int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
   NF_TRY(check_ready(f, out_x, rows));
   if (rows == 0) return NF_OK;

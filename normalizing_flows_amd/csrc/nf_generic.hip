@@ -652,6 +652,58 @@ int launch_base_sample(float* out, long long rows, int D, int base, unsigned lon
   return NF_OK;
 }
 
+// ------------------------------------------------------------------------
+// Toy-density generators: the reference's host-side tfp samplers
+// (src/densities/banana.py:31-41, energies.py:47-127, gaussian_blobs.py:34-59) as one kernel.
+// One Philox4x32-10 call per row (counter = row, third counter word 0x44454E53): words 0,1 ->
+// a Box-Muller pair (n0, n1), word 2 -> a uniform, word 3 -> component bits.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void density_sample_kernel(float2* __restrict__ out, long long rows, int density,
+                                                            unsigned long long seed) {
+  const float kPi = 3.14159265358979f;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    unsigned w[4];
+    philox4x32_10((unsigned)r, (unsigned)(r >> 32), 0x44454E53u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+    const float u0 = ((float)(w[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float u1 = ((float)(w[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float u2 = (float)(w[2] >> 8) * 5.9604644775390625e-08f;
+    const float rad = sqrtf(-2.f * logf(u0));
+    float sn, cs;
+    sincospif(2.f * u1, &sn, &cs);
+    const float n0 = rad * cs, n1 = rad * sn;
+    const bool pick = (w[3] & 1u) != 0u;
+    float a, b;
+    if (density == NF_DENSITY_BANANA) {               // x2 ~ N(0, sqrt 3); x1 ~ N(x2^2/3 - 2, sqrt(3)/2)
+      b = 1.7320508075688772f * n0;
+      a = b * b / 3.f - 2.f + 0.8660254037844386f * n1;
+    } else if (density == NF_DENSITY_ENERGY1) {       // z ~ N(0,2); v ~ N(+-(2 - z^2/32), 0.3); row (v, z)
+      b = 2.f * n0;
+      const float mu = 2.f - b * b / 32.f;
+      a = (pick ? mu : -mu) + 0.3f * n1;
+    } else if (density == NF_DENSITY_BLOBS) {         // 8 blobs on the circle of radius 2, sigma 0.3
+      float sk, ck;
+      sincospif((float)(w[3] & 7u) * 0.25f, &sk, &ck);
+      a = 2.f * ck + 0.3f * n0;
+      b = 2.f * sk + 0.3f * n1;
+    } else {                                          // energy2-4: x1 ~ U(-1.5 pi, 1.5 pi), x2 ~ N(m(x1), 0.5)
+      a = (u2 * 3.f - 1.5f) * kPi;
+      float m = sinpif(0.5f * a);                     // w1(z) = sin(2 pi z / 4)
+      if (density == NF_DENSITY_ENERGY3 && pick) { const float t = (a - 1.f) / 0.6f; m -= 3.f * expf(-0.5f * t * t); }
+      if (density == NF_DENSITY_ENERGY4 && pick) m += 3.f / (1.f + expf(-(a - 1.f) / 0.3f));
+      b = m + 0.5f * n0;
+    }
+    out[r] = make_float2(a, b);
+  }
+}
+
+int launch_density_sample(float* out, long long rows, int density, unsigned long long seed, hipStream_t stream) {
+  const int grid = (int)std::min<long long>(4096, (rows + 255) / 256);
+  hipLaunchKernelGGL(density_sample_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, stream,
+                     reinterpret_cast<float2*>(out), rows, density, seed);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // Streaming read of a [rows, 2] float32 matrix with the hot path's access shape (one float2
 // per lane); exists to calibrate rocprofv3's FETCH_SIZE on a known byte count
 // (MI355X_MICROARCH.md, HBM section: widths other than 16 B/lane are uncalibrated).

@@ -118,6 +118,7 @@ struct Plan {
 int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,
                          int D, int base, hipStream_t stream, int* out_grid);
 int launch_base_sample(float* out, long long rows, int D, int base, unsigned long long seed, hipStream_t stream);
+int launch_density_sample(float* out, long long rows, int density, unsigned long long seed, hipStream_t stream);
 int launch_debug_read_f2(const float* x, long long rows, float* out, hipStream_t stream);
 }  // namespace generic
 

@@ -537,3 +537,47 @@ def base_sample(base: str, rows: int, event_size: int, seed: int) -> np.ndarray:
         v[:, 0::2] = rad * np.cos(ang)
         v[:, 1::2] = rad * np.sin(ang)
     return v.reshape(-1)[:total].reshape(rows, event_size)
+
+
+def density_sample(density: str, rows: int, seed: int) -> np.ndarray:
+    """float64 restatement of nf_density_sample (same Philox words, same formulas):
+    the reference's generators src/densities/banana.py:37-41, energies.py:47-127,
+    gaussian_blobs.py:34-59 driven by libnf_hip's stream instead of JAX threefry."""
+    r = np.arange(rows, dtype=np.uint64)
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    c0, c1 = r & mask, r >> np.uint64(32)
+    c2 = np.full(rows, 0x44454E53, np.uint64)
+    c3 = np.zeros(rows, np.uint64)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = (((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask, p1 & mask,
+                          ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask, p0 & mask)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    u0 = ((c0 >> np.uint64(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    u1 = ((c1 >> np.uint64(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    u2 = (c2 >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+    rad = np.sqrt(-2.0 * np.log(u0))
+    n0, n1 = rad * np.cos(2 * np.pi * u1), rad * np.sin(2 * np.pi * u1)
+    pick = (c3 & np.uint64(1)) != 0
+    if density == "banana":
+        b = math.sqrt(3.0) * n0
+        a = b * b / 3.0 - 2.0 + math.sqrt(3.0) / 2.0 * n1
+    elif density == "energy1":
+        b = 2.0 * n0
+        mu = 2.0 - b * b / 32.0
+        a = np.where(pick, mu, -mu) + 0.3 * n1
+    elif density == "gaussian_blobs":
+        th = 2.0 * np.pi * (c3 & np.uint64(7)).astype(np.float64) / 8.0
+        a = 2.0 * np.cos(th) + 0.3 * n0
+        b = 2.0 * np.sin(th) + 0.3 * n1
+    else:
+        a = (u2 * 3.0 - 1.5) * np.pi
+        m = _w1(a)
+        if density == "energy3":
+            m = np.where(pick, m - 3.0 * np.exp(-0.5 * ((a - 1.0) / 0.6) ** 2), m)
+        elif density == "energy4":
+            m = np.where(pick, m + 3.0 / (1.0 + np.exp(-(a - 1.0) / 0.3)), m)
+        b = m + 0.5 * n0
+    return np.stack([a, b], -1)

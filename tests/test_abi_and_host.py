@@ -127,6 +127,17 @@ def test_conditioner_and_haiku_param_mapping():
     assert layers[2][0][0][0, 0] == 2 and layers[2][1][0][0, 0] == 12 and layers[1][2][0][0, 0] == 21
     with pytest.raises(ValueError):
         distrax.layers_from_haiku_params({"conv": {"w": 0, "b": 0}})
+    # weight file round trip (npz with haiku module names)
+    import tempfile
+    back = distrax.layers_to_haiku_params(layers)
+    assert sorted(back) == sorted(hk)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "flow.npz")
+        distrax.save_params(path, back)
+        again = distrax.layers_from_haiku_params(distrax.load_params(path))
+    for la, lb in zip(layers, again):
+        for (Wa, ba), (Wb, bb) in zip(la, lb):
+            assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
 
 
 def test_lowering_recognises_reference_structures_without_a_gpu():

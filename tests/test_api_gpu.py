@@ -241,3 +241,21 @@ def test_mnist_shape_sampling(distrax):
     sr = O.sample_from_z(spec, z)
     e32 = np.abs(O.sample_from_z(spec, z.astype(np.float32), np.float32) - sr).max()
     assert (np.abs(s.reshape(48, 784) - sr) <= np.maximum(tol(sr), 4 * e32)).all()
+
+
+def test_density_generators_on_device(distrax):
+    from normalizing_flows_amd import densities
+    from normalizing_flows_amd.distributions import _seed_u64
+    for name in densities.DENSITIES:
+        got = densities.sample_density(name, 2123, 50000)
+        ref = O.density_sample(name, 50000, 2123)
+        assert got.shape == (50000, 2)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), name
+    ds = densities.make_dataset_banana(seed=2123, batch_size=128, num_batches=3)     # src/real_nvp_toy_densities.py:179
+    batches = list(ds)
+    assert len(batches) == 3 and batches[0].shape == (128, 2) and not np.array_equal(batches[0], batches[1])
+    assert np.array_equal(next(densities.get_density("banana")(2123, 128, 1)), batches[0])
+    dev = next(densities.make_dataset_energy_2(seed=5, batch_size=4096, num_batches=1, device=True))
+    assert np.array_equal(dev.to_numpy(), next(densities.make_dataset_energy_2(seed=5, batch_size=4096, num_batches=1)))
+    with pytest.raises(ValueError):
+        densities.sample_density("moons", 1, 8)

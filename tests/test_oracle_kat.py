@@ -276,3 +276,21 @@ def test_philox_known_answers():
     u = O.base_sample("uniform01", 1000, 784, 5)
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.002
     assert not np.array_equal(O.base_sample("normal", 8, 2, 1), O.base_sample("normal", 8, 2, 2))
+
+
+def test_density_restatement_statistics():
+    """oracle density_sample (the Philox-driven restatement of src/densities/*.py) has the moments
+    the reference's generators imply, and agrees in distribution with make_inputs."""
+    b = O.density_sample("banana", 200000, 3)
+    assert abs(b[:, 1].std() - np.sqrt(3)) < 0.02 and abs(b[:, 0].mean() + 1.0) < 0.02
+    g = O.density_sample("gaussian_blobs", 200000, 3)
+    assert abs(np.hypot(g[:, 0], g[:, 1]).mean() - 2.0) < 0.05
+    ang = np.round(np.arctan2(g[:, 1], g[:, 0]) / (np.pi / 4)) % 8
+    assert np.abs(np.bincount(ang.astype(int), minlength=8) / 200000 - 0.125).max() < 0.01
+    e1 = O.density_sample("energy1", 200000, 3)
+    assert abs(e1[:, 1].std() - 2.0) < 0.02 and abs(np.abs(e1[:, 0]).mean() - (2 - 4 / 32)) < 0.05
+    for name in ("energy2", "energy3", "energy4"):
+        e = O.density_sample(name, 200000, 3)
+        ref = O.make_inputs(name, 200000).astype(np.float64)
+        assert abs(e[:, 0].min() + 1.5 * np.pi) < 1e-3 and abs(e[:, 0].max() - 1.5 * np.pi) < 1e-3
+        assert abs(e[:, 1].mean() - ref[:, 1].mean()) < 0.02 and abs(e[:, 1].std() - ref[:, 1].std()) < 0.02
