@@ -207,6 +207,30 @@ int nf_nll_enqueue(nf_flow* flow, const float* x_dev, int64_t rows_local, int64_
                    float* out_log_prob_dev, int slot);
 int nf_nll_result(nf_flow* flow, int slot, double* out_nll);
 
+/* ---- training step (masked affine flows with the fused kernel) --------- */
+typedef enum nf_optimizer_kind { NF_OPT_SGD = 0, NF_OPT_ADAM = 1 } nf_optimizer_kind;
+typedef struct nf_optimizer {
+  int32_t kind;          /* nf_optimizer_kind */
+  float learning_rate;
+  float beta1, beta2, eps; /* optax.adam defaults 0.9, 0.999, 1e-8 */
+} nf_optimizer;
+
+/* Replaces jax.value_and_grad(loss) (src/real_nvp.py:297) / jax.grad(loss_fn)
+   (src/real_nvp_toy_densities.py:170): NLL of the local rows' share and d NLL / d weights in
+   the layout of nf_flow_set_weights (all-reduced over the communicator when one is attached).
+   out_grad[nf_flow_weight_count] lives where `mem` says. */
+int nf_nll_grad(nf_flow* flow, const float* x, int64_t rows_local, int64_t rows_global, double* out_nll,
+                float* out_grad, int mem);
+
+/* Replaces `update` (src/real_nvp_toy_densities.py:164-173: grad, optax.adam update, apply_updates)
+   and `sgd_update` (src/real_nvp.py:295-306): one optimisation step on the handle's weights,
+   entirely on the device.  *out_nll is the loss BEFORE the step. */
+int nf_train_step(nf_flow* flow, const float* x, int64_t rows_local, int64_t rows_global,
+                  const nf_optimizer* opt, double* out_nll, int mem);
+
+/* Current weights of the handle, layout of nf_flow_set_weights (host buffer). */
+int nf_flow_get_weights(nf_flow* flow, float* packed, size_t count);
+
 /* ---- stream timing (bench.py: HIP events on the stream the kernels run on) */
 int nf_timer_start(nf_flow* flow);
 int nf_timer_stop(nf_flow* flow, float* out_ms); /* synchronises on the stop event */

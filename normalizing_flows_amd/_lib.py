@@ -40,6 +40,14 @@ class NFError(RuntimeError):
         self.status = status
 
 
+class Optimizer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("learning_rate", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+OPT_SGD, OPT_ADAM = 0, 1
+
+
 class FlowDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32),
@@ -93,6 +101,11 @@ PROTOTYPES = {
                          C.POINTER(C.c_double), C.c_int]),
     "nf_nll_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),
     "nf_nll_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "nf_nll_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p,
+                              C.c_int]),
+    "nf_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_double),
+                                C.c_int]),
+    "nf_flow_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "nf_timer_start": (C.c_int, [C.c_void_p]),
     "nf_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "nf_debug_read_f2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -1,0 +1,415 @@
+// Backward pass of the masked affine coupling chain (variant B, D = 2, conditioner
+// 2 -> 64 -> 64 -> 2): d(NLL)/d(weights), i.e. the jax.grad(loss_fn) inside the reference's
+// `update` (src/real_nvp_toy_densities.py:139-173), SURVEY.md section 8f rank 2.
+//
+// No activation is stored: the flow is invertible, so the backward walk (layer 0 first, the
+// reverse of the order log_prob applies them) rebuilds each layer's input from its output while
+// it recomputes the conditioner.  One launch per layer; per 32-sample tile a wave runs three
+// 64x64 products on the f32 MFMA, all operands staying in registers except one transpose
+// through LDS:
+//   1. recompute  a2 = W2^T h1 + b2          (as the forward kernel; h1 generated from x_c)
+//   2. lane-local: (shift, log_scale), the inverse affine map, the output gradients, and
+//      g2 = (W3 g_out) * [a2 > 0]  on the accumulator
+//   3. g1 = W2 g2                            (accumulator-fed MFMA pass, k in accumulator order)
+//   4. dW2 += h1 (x) g2 summed over the tile's samples (MFMA whose K dimension is the sample
+//      index: h1 regenerated with samples on K, g2 read back transposed from LDS)
+// Bias / first / last Linear gradients accumulate lane-locally.  Every wave keeps its partial
+// gradient in registers across all its tiles and writes it once; a second kernel adds the
+// waves' partials in a fixed order, scales by 1/rows_global and scatters into the canonical
+// (nf_flow_set_weights) layout.
+#include "nf_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace nf {
+namespace affine2d_bwd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kReluShift = 64;
+
+static inline int unit_of(int m, int r, int h) { return 32 * m + 8 * (r >> 2) + 4 * h + (r & 3); }
+
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, float* img) {
+  memset(img, 0, sizeof(float) * kImageFloats);
+  for (int s = 0; s < 32; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int m = 0; m < 2; ++m)
+        img[oA2 + (s * 64 + lane) * 2 + m] = ldexpf(W2[(2 * s + (lane >> 5)) * 64 + 32 * m + (lane & 31)], kReluShift);
+  for (int m = 0; m < 2; ++m)
+    for (int r = 0; r < 16; ++r)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int mo = 0; mo < 2; ++mo)
+          img[oA2T + ((m * 16 + r) * 64 + lane) * 2 + mo] = W2[(32 * mo + (lane & 31)) * 64 + unit_of(m, r, lane >> 5)];
+  for (int k = 0; k < 64; ++k) {
+    img[oW1B1 + 2 * k + 0] = ldexpf(W1[cond_dim * 64 + k], -kReluShift);
+    img[oW1B1 + 2 * k + 1] = ldexpf(b1[k], -kReluShift);
+  }
+  for (int h = 0; h < 2; ++h)
+    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) {
+        const int u = unit_of(m, r, h), q = (h * 2 + m) * 16 + r;
+        img[oW1acc + q] = W1[cond_dim * 64 + u];
+        img[oB1acc + q] = b1[u];
+        img[oB2 + q] = b2[u];
+        img[oW3 + 2 * q + 0] = W3[u * 2 + 0];
+        img[oW3 + 2 * q + 1] = W3[u * 2 + 1];
+      }
+  img[oB3 + 0] = b3[0];
+  img[oB3 + 1] = b3[1];
+}
+
+// canonical (per layer: W1[2][64], b1[64], W2[64][64], b2[64], W3[64][2], b3[2]) -> index into a
+// wave's partial block, and the factor that undoes the 2^-64 carried by h1 in dW2
+void build_gather_map(int cond_dim, int* map, float* scale) {
+  for (int e = 0; e < kCanonFloats; ++e) { map[e] = -1; scale[e] = 1.f; }
+  const int cW1 = 0, cb1 = 128, cW2 = 192, cb2 = 192 + 4096, cW3 = cb2 + 64, cb3 = cW3 + 128;
+  for (int mk = 0; mk < 2; ++mk)
+    for (int mj = 0; mj < 2; ++mj)
+      for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int k = unit_of(mk, r, lane >> 5), j = 32 * mj + (lane & 31);
+          map[cW2 + k * 64 + j] = pW2 + ((mk * 2 + mj) * 16 + r) * 64 + lane;
+          scale[cW2 + k * 64 + j] = ldexpf(1.f, kReluShift);
+        }
+  for (int h = 0; h < 2; ++h)
+    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) {
+        const int u = unit_of(m, r, h), q = (h * 2 + m) * 16 + r;
+        map[cb2 + u] = pB2 + q;
+        map[cW3 + 2 * u + 0] = pW3 + 2 * q + 0;
+        map[cW3 + 2 * u + 1] = pW3 + 2 * q + 1;
+        map[cb1 + u] = pB1 + q;
+        map[cW1 + cond_dim * 64 + u] = pW1 + q;  // the masked input row has zero gradient
+      }
+  map[cb3 + 0] = pB3 + 0;
+  map[cb3 + 1] = pB3 + 1;
+}
+
+struct Params {
+  const float* img;   // this layer's image (kImageFloats)
+  float2* v;          // [rows] state: in = the layer's output, out = its input
+  float2* G;          // [rows] d(loss_i)/d(state); read unless `first`
+  float* partials;    // [waves][kPartialFloats]
+  long long rows;
+  int cond_dim;
+  int first;          // G := v (the base density's gradient) instead of reading G
+};
+
+__device__ __forceinline__ float add_halves(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ f32x16 lds_f32x16(const float* p) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 a = q[0], b = q[1], c = q[2], d = q[3];
+  f32x16 v;
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+  return v;
+}
+__device__ __forceinline__ float exp_f32(float x) {
+  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float hi = x * kLog2eHi;
+  const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
+  const float e = __builtin_amdgcn_exp2f(hi);
+  return fmaf(e, lo * kLn2, e);
+}
+// sum over the 32 lanes of this lane's half-wave
+__device__ __forceinline__ float half_sum(float x) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+
+constexpr int kGT = 32 * 65;          // transposed g2 tile, padded rows
+constexpr int kWaveScratch = kGT + 32;  // + the tile's conditioning values
+
+__global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.img);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int q = tid; q < kImageFloats / 4; q += 256) dst[q] = src[q];
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  float* gT = lds + kImageFloats + wave * kWaveScratch;
+  float* cbuf = gT + kGT;
+  const float* L = lds;
+  const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;
+  const float2* a2t = reinterpret_cast<const float2*>(L + oA2T) + lane;
+  const float2* w1b1 = reinterpret_cast<const float2*>(L + oW1B1);
+  const int hq = h * 32;  // offset of this half's [m][r] block in the accumulator-order images
+
+  f32x16 dW2[2][2];
+  float db2[2][16], dW3s[2][16], dW3l[2][16], db1[2][16], dw1[2][16];
+  float db3s = 0.f, db3l = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dW2[a][0][r] = 0.f; dW2[a][1][r] = 0.f;
+      db2[a][r] = 0.f; dW3s[a][r] = 0.f; dW3l[a][r] = 0.f; db1[a][r] = 0.f; dw1[a][r] = 0.f;
+    }
+
+  const long long rows = p.rows;
+  const long long tiles = (rows + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
+    const long long idx = tile * 32 + i;
+    const bool valid = idx < rows;
+    float2 v = make_float2(0.f, 0.f), G = make_float2(0.f, 0.f);
+    if (valid) {
+      v = p.v[idx];
+      G = p.first ? v : p.G[idx];
+    }
+    const float c = p.cond_dim ? v.y : v.x;
+    const float tp = p.cond_dim ? v.x : v.y;
+    float Gc = p.cond_dim ? G.y : G.x;
+    const float Gtp = p.cond_dim ? G.x : G.y;
+
+    // 1. a2 = W2^T relu(w1 c + b1) + b2
+    f32x16 acc[2];
+    {
+      const f32x16 bias0 = lds_f32x16(L + oB2 + hq);
+      const f32x16 bias1 = lds_f32x16(L + oB2 + hq + 16);
+      const float2 a = a2[0];
+      const float2 wb = w1b1[h];
+      const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
+    }
+#pragma unroll 8
+    for (int s = 1; s < 32; ++s) {
+      const float2 a = a2[s * 64];
+      const float2 wb = w1b1[2 * s + h];
+      const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
+    }
+
+    // 2. (shift, log_scale), undo the affine map, gradients of the layer's two outputs
+    const float2* w3 = reinterpret_cast<const float2*>(L + oW3) + hq;
+    float ps = 0.f, pl = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 w = w3[m * 16 + r];
+        const float hv = fmaxf(acc[m][r], 0.f);
+        ps = fmaf(hv, w.x, ps);
+        pl = fmaf(hv, w.y, pl);
+      }
+    const float shift = add_halves(ps) + L[oB3 + 0];
+    const float ls = add_halves(pl) + L[oB3 + 1];
+    const float e = exp_f32(ls);
+    const float tpm = tp - shift;
+    const float t = tpm * exp_f32(-ls);            // the layer's input on the transformed dim
+    const float g_s = Gtp;                          // d loss / d shift
+    const float g_ls = valid ? fmaf(Gtp, tpm, -1.f) : 0.f;  // t e^ls = t' - shift; -1 from the -log_scale term
+    const float Gt = Gtp * e;
+    db3s += h == 0 ? g_s : 0.f;
+    db3l += h == 0 ? g_ls : 0.f;
+
+    // g2 = (W3 g_out) * [a2 > 0]; kept in `acc` as the next pass's operand and transposed into LDS
+    if (h == 0) cbuf[i] = c;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 w = w3[m * 16 + r];
+        const float a = acc[m][r];
+        const float hv = fmaxf(a, 0.f);
+        const float ga = a > 0.f ? fmaf(w.x, g_s, w.y * g_ls) : 0.f;
+        db2[m][r] += ga;
+        dW3s[m][r] = fmaf(hv, g_s, dW3s[m][r]);
+        dW3l[m][r] = fmaf(hv, g_ls, dW3l[m][r]);
+        acc[m][r] = ga;
+        gT[i * 65 + 32 * m + 8 * (r >> 2) + 4 * h + (r & 3)] = ga;
+      }
+
+    // 3. g1 = W2 g2 (k-steps in accumulator order)
+    f32x16 g1[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { g1[0][r] = 0.f; g1[1][r] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 a = a2t[(m * 16 + r) * 64];
+        g1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[m][r], g1[0], 0, 0, 0);
+        g1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[m][r], g1[1], 0, 0, 0);
+      }
+    float gcm = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float w1a = L[oW1acc + hq + m * 16 + r], b1a = L[oB1acc + hq + m * 16 + r];
+        const float gz = fmaf(w1a, c, b1a) > 0.f ? g1[m][r] : 0.f;
+        gcm = fmaf(gz, w1a, gcm);
+        db1[m][r] += gz;
+        dw1[m][r] = fmaf(gz, c, dw1[m][r]);
+      }
+    Gc += add_halves(gcm);
+
+    // 4. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float ci = cbuf[2 * s + h];
+      const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
+      const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
+      const float a1 = __builtin_amdgcn_fmed3f(fmaf(ci, wb1.x, wb1.y), 0.f, 1.f);
+      const float b0 = gT[(2 * s + h) * 65 + i], b1v = gT[(2 * s + h) * 65 + 32 + i];
+      dW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dW2[0][0], 0, 0, 0);
+      dW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, dW2[0][1], 0, 0, 0);
+      dW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dW2[1][0], 0, 0, 0);
+      dW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, dW2[1][1], 0, 0, 0);
+    }
+
+    if (h == 0 && valid) {
+      p.v[idx] = p.cond_dim ? make_float2(t, c) : make_float2(c, t);
+      p.G[idx] = p.cond_dim ? make_float2(Gt, Gc) : make_float2(Gc, Gt);
+    }
+  }
+
+  // one partial gradient per wave
+  float* P = p.partials + ((size_t)blockIdx.x * 4 + wave) * kPartialFloats;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[pW2 + ((a * 2 + b) * 16 + r) * 64 + lane] = dW2[a][b][r];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = hq + m * 16 + r;
+      const float s2 = half_sum(db2[m][r]), s3s = half_sum(dW3s[m][r]), s3l = half_sum(dW3l[m][r]);
+      const float s1 = half_sum(db1[m][r]), sw = half_sum(dw1[m][r]);
+      if (i == 0) {
+        P[pB2 + q] = s2;
+        P[pW3 + 2 * q + 0] = s3s;
+        P[pW3 + 2 * q + 1] = s3l;
+        P[pB1 + q] = s1;
+        P[pW1 + q] = sw;
+      }
+    }
+  const float t3s = half_sum(db3s), t3l = half_sum(db3l);
+  if (lane == 0) { P[pB3 + 0] = t3s; P[pB3 + 1] = t3l; }
+}
+
+// grad[e] = scale[e] / rows_global * sum over waves of partial[w][map[e]], waves added in a fixed order
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ partials, int waves,
+                                                     const int* __restrict__ map, const float* __restrict__ scale,
+                                                     float* __restrict__ grad, float inv_rows) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kCanonFloats) return;
+  const int src = map[e];
+  float s = 0.f;
+  if (src >= 0) {
+    float c = 0.f;  // Kahan: 1024 partials of very different magnitude
+    for (int w = 0; w < waves; ++w) {
+      const float y = partials[(size_t)w * kPartialFloats + src] - c;
+      const float t = s + y;
+      c = (t - s) - y;
+      s = t;
+    }
+  }
+  grad[e] = s * scale[e] * inv_rows;
+}
+
+int grid_blocks() { return 256; }
+
+int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
+                 hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds_bytes = (size_t)(kImageFloats + 4 * kWaveScratch) * sizeof(float);
+  if (!attr_set) {
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  Params p;
+  p.img = img;
+  p.v = reinterpret_cast<float2*>(v);
+  p.G = reinterpret_cast<float2*>(G);
+  p.partials = partials;
+  p.rows = rows;
+  p.cond_dim = cond_dim;
+  p.first = first;
+  hipLaunchKernelGGL(layer_kernel, dim3(grid_blocks()), dim3(256), lds_bytes, stream, p);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+int launch_gather(const float* partials, const int* map, const float* scale, float* grad, long long rows_global,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(gather_kernel, dim3((kCanonFloats + 255) / 256), dim3(256), 0, stream, partials,
+                     grid_blocks() * 4, map, scale, grad, 1.0f / (float)rows_global);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+}  // namespace affine2d_bwd
+
+// ---------------------------------------------------------------------------
+// optimiser and image refresh on the canonical weight vector
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                   float b1, float b2, float eps, float c1, float c2) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  // optax.adam (src/real_nvp_toy_densities.py:162): m, v moments, bias-corrected by c1 = 1-b1^t, c2 = 1-b2^t
+  const float ge = g[e];
+  const float me = b1 * m[e] + (1.f - b1) * ge;
+  const float ve = b2 * v[e] + (1.f - b2) * ge * ge;
+  m[e] = me;
+  v[e] = ve;
+  w[e] -= lr * (me / c1) / (sqrtf(ve / c2) + eps);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, size_t n, float lr) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) w[e] -= lr * g[e];  // src/real_nvp.py:298
+}
+
+// image[i] = canon[src[i]] * 2^shift[i]  (src < 0: 0)
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ canon, const int* __restrict__ src,
+                                                     const signed char* __restrict__ shift, float* __restrict__ img,
+                                                     size_t n) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int s = src[e];
+  img[e] = s < 0 ? 0.f : ldexpf(canon[s], (int)shift[e]);
+}
+
+int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                long long step, hipStream_t stream) {
+  const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2,
+                     eps, c1, c2);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream) {
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, n, lr);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, canon, src, shift, img, n);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+}  // namespace nf

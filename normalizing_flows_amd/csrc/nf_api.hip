@@ -124,6 +124,21 @@ struct nf_flow {
   size_t weight_count = 0;
   float* d_wimg = nullptr;  // path-specific packed weights
   generic::Plan plan;       // PATH_GENERIC
+  std::vector<float> h_weights;  // canonical weights as last set from the host
+  // training state (PATH_AFFINE2D_H64; allocated on first use)
+  struct Train {
+    float *d_canon = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
+    float* d_bwd_img = nullptr;     // [L][affine2d_bwd::kImageFloats]
+    float* d_partials = nullptr;    // [waves][kPartialFloats]
+    int* d_gmap[2] = {nullptr, nullptr};      // gather maps for cond_dim 0 / 1
+    float* d_gscale[2] = {nullptr, nullptr};
+    int *d_fsrc = nullptr, *d_bsrc = nullptr;                // image <- canon maps (forward / backward images)
+    signed char *d_fshift = nullptr, *d_bshift = nullptr;
+    float *d_state_v = nullptr, *d_state_g = nullptr;
+    long long state_rows = 0;
+    long long step = 0;
+    bool ready = false, dirty = false;  // dirty: device weights are newer than h_weights
+  } train;
   // staging for NF_MEM_HOST calls and for chains longer than one launch
   float *d_x = nullptr, *d_y = nullptr, *d_ld = nullptr, *d_lp = nullptr;
   long long stage_rows = 0;
@@ -346,6 +361,13 @@ void nf_flow_destroy(nf_flow* f) {
   }
   if (f->side) hipStreamDestroy(f->side);
   hipFree(f->d_wimg);
+  {
+    nf_flow::Train& t = f->train;
+    hipFree(t.d_canon); hipFree(t.d_grad); hipFree(t.d_m); hipFree(t.d_v); hipFree(t.d_bwd_img);
+    hipFree(t.d_partials); hipFree(t.d_gmap[0]); hipFree(t.d_gmap[1]); hipFree(t.d_gscale[0]);
+    hipFree(t.d_gscale[1]); hipFree(t.d_fsrc); hipFree(t.d_bsrc); hipFree(t.d_fshift); hipFree(t.d_bshift);
+    hipFree(t.d_state_v); hipFree(t.d_state_g);
+  }
   f->plan.release();
   hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp);
   hipFree(f->d_block_sums); hipFree(f->d_sum);
@@ -368,6 +390,8 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
   linear_shapes(d, in, out);
   size_t per_layer = 0;
   for (size_t j = 0; j < in.size(); ++j) per_layer += (size_t)in[j] * out[j] + out[j];
+  f->h_weights.assign(packed, packed + count);
+  f->train.dirty = false;
   std::vector<float> img;
   if (f->path == PATH_AFFINE2D_H64) {
     img.resize((size_t)d.num_layers * affine2d::kLayerFloats);
@@ -408,6 +432,15 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
   NF_HIP(hipMalloc(&f->d_wimg, img.size() * sizeof(float)));
   NF_HIP(hipMemcpy(f->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   f->have_weights = true;
+  if (f->train.ready) {  // a training state exists: restart it from the new weights
+    NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
+    NF_HIP(hipMemset(f->train.d_m, 0, count * sizeof(float)));
+    NF_HIP(hipMemset(f->train.d_v, 0, count * sizeof(float)));
+    f->train.step = 0;
+    NF_TRY(launch_repack(f->train.d_canon, f->train.d_bsrc, f->train.d_bshift, f->train.d_bwd_img,
+                         (size_t)d.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
+  }
   return NF_OK;
 }
 
@@ -656,6 +689,213 @@ int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev) {
   if (!x_dev || !out_dev || rows < 1) { set_error("bad argument"); return NF_ERR_INVALID; }
   NF_TRY(generic::launch_debug_read_f2(x_dev, rows, out_dev, nullptr));
   NF_HIP(hipDeviceSynchronize());
+  return NF_OK;
+}
+
+}  // extern "C"
+
+namespace nf {
+
+// image <- canonical maps, derived from the pack functions themselves: pack a layer whose
+// "weights" are their own canonical index + 1 and read back which index (and which power of
+// two) landed in every image element.
+template <typename PackFn>
+static void derive_repack_map(PackFn pack, int image_floats, int cond_dim, int layer, std::vector<int>& src,
+                              std::vector<signed char>& shift) {
+  std::vector<float> ids(affine2d_bwd::kCanonFloats);
+  for (int e = 0; e < affine2d_bwd::kCanonFloats; ++e) ids[e] = (float)(e + 1);
+  const float* W1 = ids.data();
+  const float* b1 = W1 + 128;
+  const float* W2 = b1 + 64;
+  const float* b2 = W2 + 4096;
+  const float* W3 = b2 + 64;
+  const float* b3 = W3 + 128;
+  std::vector<float> img(image_floats);
+  pack(W1, b1, W2, b2, W3, b3, cond_dim, img.data());
+  for (int e = 0; e < image_floats; ++e) {
+    const float v = img[e];
+    int sh = 0;
+    float id = v;
+    if (v == 0.f) { src.push_back(-1); shift.push_back(0); continue; }
+    if (v > 1e12f) { sh = 64; id = ldexpf(v, -64); }
+    else if (v < 1e-12f) { sh = -64; id = ldexpf(v, 64); }
+    src.push_back(layer * affine2d_bwd::kCanonFloats + (int)(id + 0.5f) - 1);
+    shift.push_back((signed char)sh);
+  }
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& host) {
+  NF_HIP(hipMalloc(dst, host.size() * sizeof(T)));
+  NF_HIP(hipMemcpy(*dst, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return NF_OK;
+}
+
+static int ensure_train(nf_flow* f, long long rows) {
+  if (f->path != PATH_AFFINE2D_H64) {
+    set_error("the backward pass is built for the fused masked-affine flow (D = 2, conditioner 2-64-64-2) only");
+    return NF_ERR_UNSUPPORTED;
+  }
+  nf_flow::Train& t = f->train;
+  const nf_flow_desc& d = f->desc;
+  const size_t n = f->weight_count;
+  if (!t.ready) {
+    NF_HIP(hipMalloc(&t.d_canon, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_m, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_v, n * sizeof(float)));
+    NF_HIP(hipMemcpy(t.d_canon, f->h_weights.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
+    NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_bwd_img, (size_t)d.num_layers * affine2d_bwd::kImageFloats * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_partials, (size_t)affine2d_bwd::grid_blocks() * 4 * affine2d_bwd::kPartialFloats * sizeof(float)));
+    for (int c = 0; c < 2; ++c) {
+      std::vector<int> map(affine2d_bwd::kCanonFloats);
+      std::vector<float> scale(affine2d_bwd::kCanonFloats);
+      affine2d_bwd::build_gather_map(c, map.data(), scale.data());
+      NF_TRY(upload(&t.d_gmap[c], map));
+      NF_TRY(upload(&t.d_gscale[c], scale));
+    }
+    std::vector<int> fsrc, bsrc;
+    std::vector<signed char> fshift, bshift;
+    for (int l = 0; l < d.num_layers; ++l) {
+      const int cond = (d.first_mask_parity + l) & 1;
+      derive_repack_map(affine2d::pack_layer, affine2d::kLayerFloats, cond, l, fsrc, fshift);
+      derive_repack_map(affine2d_bwd::pack_layer, affine2d_bwd::kImageFloats, cond, l, bsrc, bshift);
+    }
+    NF_TRY(upload(&t.d_fsrc, fsrc));
+    NF_TRY(upload(&t.d_fshift, fshift));
+    NF_TRY(upload(&t.d_bsrc, bsrc));
+    NF_TRY(upload(&t.d_bshift, bshift));
+    NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
+                         (size_t)d.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    t.step = 0;
+    t.ready = true;
+  }
+  if (rows > t.state_rows) {
+    hipFree(t.d_state_v); hipFree(t.d_state_g);
+    t.d_state_v = t.d_state_g = nullptr;
+    t.state_rows = 0;
+    NF_HIP(hipMalloc(&t.d_state_v, sizeof(float) * 2 * rows));
+    NF_HIP(hipMalloc(&t.d_state_g, sizeof(float) * 2 * rows));
+    t.state_rows = rows;
+  }
+  return NF_OK;
+}
+
+// forward (z and the NLL sum) + backward walk + gradient gather (+ all-reduce); leaves d NLL / d w in
+// train.d_grad and the NLL of this call in ring slot 0
+static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local, long long rows_global) {
+  nf_flow::Train& t = f->train;
+  const nf_flow_desc& d = f->desc;
+  const int slot = 0;
+  double* sums = f->d_block_sums + (size_t)slot * 4096;
+  if (f->tail_pending[slot]) NF_HIP(hipStreamWaitEvent(f->stream, f->ev_tail[slot], 0));
+  int grid = 0;
+  {
+    ChainIO io;
+    memset(&io, 0, sizeof(io));
+    io.rows = rows_local;
+    io.layer_begin = 0;
+    io.layer_end = d.num_layers;
+    direction_flags(NF_DIR_CHAIN_FORWARD, &io.descending, &io.inverse_op);
+    io.x = x_dev;
+    io.y = t.d_state_v;
+    io.block_sums = sums;
+    io.add_base = 1;
+    NF_TRY(run_chain_device(f, io, &grid));
+  }
+  NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));
+  NF_HIP(hipStreamWaitEvent(f->side, f->ev_kernel[slot], 0));
+  NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->side));
+  if (f->comm) NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_sum + slot, f->side));
+  NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->side));
+  NF_HIP(hipEventRecord(f->ev_tail[slot], f->side));
+  f->tail_pending[slot] = true;
+  f->ring_rows[slot] = rows_global;
+  // backward: the layer log_prob applied last (layer 0) first
+  for (int l = 0; l < d.num_layers; ++l) {
+    const int cond = (d.first_mask_parity + l) & 1;
+    NF_TRY(affine2d_bwd::launch_layer(t.d_bwd_img + (size_t)l * affine2d_bwd::kImageFloats, t.d_state_v, t.d_state_g,
+                                      t.d_partials, rows_local, cond, l == 0, f->stream));
+    NF_TRY(affine2d_bwd::launch_gather(t.d_partials, t.d_gmap[cond], t.d_gscale[cond],
+                                       t.d_grad + (size_t)l * affine2d_bwd::kCanonFloats, rows_global, f->stream));
+  }
+  if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+  return NF_OK;
+}
+
+static int stage_train_input(nf_flow* f, const float* x, long long rows, int mem, const float** x_dev) {
+  if (mem == NF_MEM_DEVICE) {
+    NF_TRY(check_device_ptr(x, "x"));
+    *x_dev = x;
+    return NF_OK;
+  }
+  NF_TRY(ensure_stage(f, rows));
+  NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * f->desc.event_dim, hipMemcpyHostToDevice, f->stream));
+  *x_dev = f->d_x;
+  return NF_OK;
+}
+
+}  // namespace nf
+
+extern "C" {
+
+int nf_nll_grad(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, double* out_nll,
+                float* out_grad, int mem) {
+  NF_TRY(check_ready(f, x, rows_local));
+  if (rows_local < 1 || rows_global < rows_local) { set_error("need 1 <= rows_local <= rows_global"); return NF_ERR_INVALID; }
+  if (!out_grad) { set_error("out_grad is NULL"); return NF_ERR_INVALID; }
+  NF_TRY(ensure_train(f, rows_local));
+  const float* x_dev = nullptr;
+  NF_TRY(stage_train_input(f, x, rows_local, mem, &x_dev));
+  NF_TRY(enqueue_nll_grad(f, x_dev, rows_local, rows_global));
+  NF_HIP(hipMemcpyAsync(out_grad, f->train.d_grad, f->weight_count * sizeof(float),
+                        mem == NF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, f->stream));
+  NF_TRY(nf_flow_synchronize(f));
+  if (out_nll) NF_TRY(nf_nll_result(f, 0, out_nll));
+  return NF_OK;
+}
+
+int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, const nf_optimizer* opt,
+                  double* out_nll, int mem) {
+  NF_TRY(check_ready(f, x, rows_local));
+  if (!opt) { set_error("opt is NULL"); return NF_ERR_INVALID; }
+  if (opt->kind != NF_OPT_SGD && opt->kind != NF_OPT_ADAM) { set_error("unknown optimizer %d", opt->kind); return NF_ERR_INVALID; }
+  if (rows_local < 1 || rows_global < rows_local) { set_error("need 1 <= rows_local <= rows_global"); return NF_ERR_INVALID; }
+  NF_TRY(ensure_train(f, rows_local));
+  nf_flow::Train& t = f->train;
+  const float* x_dev = nullptr;
+  NF_TRY(stage_train_input(f, x, rows_local, mem, &x_dev));
+  NF_TRY(enqueue_nll_grad(f, x_dev, rows_local, rows_global));
+  t.step += 1;
+  if (opt->kind == NF_OPT_ADAM)
+    NF_TRY(launch_adam(t.d_canon, t.d_grad, t.d_m, t.d_v, f->weight_count, opt->learning_rate, opt->beta1, opt->beta2,
+                       opt->eps, t.step, f->stream));
+  else
+    NF_TRY(launch_sgd(t.d_canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream));
+  NF_TRY(launch_repack(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg,
+                       (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
+  NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
+                       (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+  t.dirty = true;
+  if (out_nll) {
+    NF_TRY(nf_flow_synchronize(f));
+    NF_TRY(nf_nll_result(f, 0, out_nll));
+  }
+  return NF_OK;
+}
+
+int nf_flow_get_weights(nf_flow* f, float* packed, size_t count) {
+  if (!f || !packed) { set_error("bad argument"); return NF_ERR_INVALID; }
+  if (!f->have_weights) { set_error("nf_flow_set_weights has not been called"); return NF_ERR_STATE; }
+  if (count != f->weight_count) { set_error("expected room for %zu weights, got %zu", f->weight_count, count); return NF_ERR_INVALID; }
+  if (f->train.ready && f->train.dirty) {
+    NF_TRY(nf_flow_synchronize(f));
+    NF_HIP(hipMemcpy(f->h_weights.data(), f->train.d_canon, count * sizeof(float), hipMemcpyDeviceToHost));
+    f->train.dirty = false;
+  }
+  memcpy(packed, f->h_weights.data(), count * sizeof(float));
   return NF_OK;
 }
 

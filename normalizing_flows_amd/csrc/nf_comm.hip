@@ -86,6 +86,13 @@ int comm_allreduce_sum_f64(nf_comm* c, double* dev_value, hipStream_t stream) {
   return NF_OK;
 }
 
+int comm_allreduce_sum_f32(nf_comm* c, float* dev_values, size_t count, hipStream_t stream) {
+  if (!c || !c->comm) { set_error("communicator is not initialised"); return NF_ERR_COMM; }
+  const int rc = g_rccl.all_reduce(dev_values, dev_values, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, stream);
+  if (rc != 0) return rccl_fail(rc, "ncclAllReduce");
+  return NF_OK;
+}
+
 }  // namespace nf
 
 extern "C" {

@@ -69,6 +69,43 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
 int max_grid();  // blocks the launch uses at most (= size of block_sums needed)
 }  // namespace affine2d
 
+// ---- backward of path 1 (training step) ---------------------------------
+namespace affine2d_bwd {
+// per-layer canonical weights: W1[2][64], b1[64], W2[64][64], b2[64], W3[64][2], b3[2]
+constexpr int kCanonFloats = 4482;
+// LDS image of one layer for the backward kernel (floats)
+constexpr int oA2 = 0;              // [32 kstep][64 lane][2 mtile]    W2 * 2^64 (forward recompute)
+constexpr int oA2T = 4096;          // [32 kstep'][64 lane][2 mtile']  W2 rows, k in accumulator order
+constexpr int oW1B1 = 8192;         // [64 k][2]                        (w1, b1) * 2^-64
+constexpr int oW1acc = oW1B1 + 128; // [2 half][2 mtile][16 reg]        w1 in accumulator order
+constexpr int oB1acc = oW1acc + 64;
+constexpr int oB2 = oB1acc + 64;
+constexpr int oW3 = oB2 + 64;       // [2 half][2 mtile][16 reg][2]
+constexpr int oB3 = oW3 + 128;
+constexpr int kImageFloats = oB3 + 8;  // 8648
+// one wave's partial gradient (floats)
+constexpr int pW2 = 0;              // [2 mk][2 mj][16 reg][64 lane]  (still carries 2^-64)
+constexpr int pB2 = 4096;           // [2 half][2 mtile][16 reg]
+constexpr int pW3 = pB2 + 64;       // [...][2]
+constexpr int pB1 = pW3 + 128;
+constexpr int pW1 = pB1 + 64;
+constexpr int pB3 = pW1 + 64;
+constexpr int kPartialFloats = pB3 + 4;  // 4420
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, float* image);
+void build_gather_map(int cond_dim, int* map /*[kCanonFloats]*/, float* scale);
+int grid_blocks();
+int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
+                 hipStream_t stream);
+int launch_gather(const float* partials, const int* map, const float* scale, float* grad, long long rows_global,
+                  hipStream_t stream);
+}  // namespace affine2d_bwd
+int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                long long step, hipStream_t stream);
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream);
+int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
+                  hipStream_t stream);
+
 // ---- path 1b: masked RQS coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2*(3K+1) ----------
 namespace rqs2d {
 // image of ONE layer (floats); layers are streamed through an LDS double buffer
@@ -127,5 +164,6 @@ int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStrea
 
 // ---- RCCL (dlopen'ed) ---------------------------------------------------------
 int comm_allreduce_sum_f64(nf_comm* comm, double* dev_value, hipStream_t stream);
+int comm_allreduce_sum_f32(nf_comm* comm, float* dev_values, size_t count, hipStream_t stream);
 
 }  // namespace nf

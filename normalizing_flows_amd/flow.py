@@ -265,6 +265,63 @@ class CouplingFlow:
         check(self._lib.nf_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    # -- training step (masked affine flows on the fused kernel) ------------------
+    def unpack_weights(self, packed: np.ndarray) -> List[List[Tuple[np.ndarray, np.ndarray]]]:
+        """Layer-major float32 vector (nf_flow_set_weights layout) -> per-layer [(W, b), ...]."""
+        shapes = self.config.linear_shapes()
+        out, pos = [], 0
+        for _ in range(self.config.num_layers):
+            layer = []
+            for fi, fo in shapes:
+                W = packed[pos:pos + fi * fo].reshape(fi, fo).copy(); pos += fi * fo
+                b = packed[pos:pos + fo].copy(); pos += fo
+                layer.append((W, b))
+            out.append(layer)
+        if pos != packed.size:
+            raise ValueError("packed vector has the wrong length")
+        return out
+
+    def _weight_count(self) -> int:
+        return sum(fi * fo + fo for fi, fo in self.config.linear_shapes()) * self.config.num_layers
+
+    def get_weights(self) -> List[List[Tuple[np.ndarray, np.ndarray]]]:
+        n = self._weight_count()
+        packed = np.empty(n, np.float32)
+        check(self._lib.nf_flow_get_weights(self._h, packed.ctypes.data_as(C.c_void_p), n))
+        return self.unpack_weights(packed)
+
+    def nll_grad(self, x: ArrayLike, rows_global: Optional[int] = None):
+        """(NLL, d NLL / d weights as per-layer [(dW, db), ...]) -- jax.value_and_grad(loss)."""
+        rows = self._rows_of(x)
+        rows_global = rows if rows_global is None else int(rows_global)
+        n = self._weight_count()
+        grad = np.empty(n, np.float32)
+        nll = C.c_double()
+        if _is_device(x):
+            gd = DeviceArray((n,))
+            check(self._lib.nf_nll_grad(self._h, x.ptr, rows, rows_global, C.byref(nll), gd.ptr, _lib.MEM_DEVICE))
+            grad = gd.to_numpy()
+        else:
+            xh = self._host(x)
+            check(self._lib.nf_nll_grad(self._h, xh.ctypes.data_as(C.c_void_p), rows, rows_global, C.byref(nll),
+                                        grad.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+        return nll.value, self.unpack_weights(grad)
+
+    def train_step(self, x: ArrayLike, optimizer: "_lib.Optimizer", rows_global: Optional[int] = None,
+                   want_nll: bool = True) -> Optional[float]:
+        """One optimiser step on the handle's weights; returns the NLL before the step."""
+        rows = self._rows_of(x)
+        rows_global = rows if rows_global is None else int(rows_global)
+        nll = C.c_double()
+        out = C.byref(nll) if want_nll else None
+        if _is_device(x):
+            check(self._lib.nf_train_step(self._h, x.ptr, rows, rows_global, C.byref(optimizer), out, _lib.MEM_DEVICE))
+        else:
+            xh = self._host(x)
+            check(self._lib.nf_train_step(self._h, xh.ctypes.data_as(C.c_void_p), rows, rows_global,
+                                          C.byref(optimizer), out, _lib.MEM_HOST))
+        return nll.value if want_nll else None
+
     def attach_comm(self, comm) -> None:
         check(self._lib.nf_flow_attach_comm(self._h, comm._h if comm is not None else None))
         self._comm = comm

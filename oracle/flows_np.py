@@ -581,3 +581,74 @@ def density_sample(density: str, rows: int, seed: int) -> np.ndarray:
             m = np.where(pick, m + 3.0 / (1.0 + np.exp(-(a - 1.0) / 0.3)), m)
         b = m + 0.5 * n0
     return np.stack([a, b], -1)
+
+
+# --------------------------------------------------------------------------
+# gradient of the NLL (the training step's jax.grad(loss_fn), src/real_nvp_toy_densities.py:164-173),
+# restated by hand for the masked affine flow: reverse-mode through the chain, float64.
+# --------------------------------------------------------------------------
+def affine_nll_and_grad(spec: FlowSpec, x, dtype=np.float64):
+    """Returns (nll, grads) with grads[l] = [(dW, db), ...] shaped like spec.layers[l].
+
+    loss = -mean_i log_prob(x_i);  relu'(0) = 0 as in jax.nn.relu."""
+    assert spec.kind == "affine" and spec.base == "normal"
+    x = np.asarray(x, dtype)
+    n = x.shape[0]
+    L = len(spec.layers)
+    # forward (Chain.forward: last layer first), remembering what the backward pass needs
+    tape = []
+    v = x
+    total_ld = np.zeros(n, dtype)
+    for l in reversed(range(L)):
+        mask = spec.masks[l]
+        masked = np.where(mask, v, dtype(0))
+        acts = [masked]
+        pre = []
+        a = masked
+        for W, b in spec.layers[l][:-1]:
+            z = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+            pre.append(z)
+            a = relu(z)
+            acts.append(a)
+        W, b = spec.layers[l][-1]
+        out = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+        shift, ls = out[:, :1], out[:, 1:2]
+        e = np.exp(ls)
+        y = np.where(mask, v, v * e + shift)
+        n_t = int((~mask).sum())
+        total_ld = total_ld + n_t * ls[:, 0]
+        tape.append((l, v, acts, pre, e, ls))
+        v = y
+    z_final = v
+    nll = np.mean(0.5 * np.sum(z_final * z_final, -1) + 0.5 * spec.event_size * math.log(2 * math.pi) - total_ld)
+    # backward
+    grads = [None] * L
+    G = z_final / n                                   # d nll / d z
+    for l, v_in, acts, pre, e, ls in reversed(tape):
+        mask = spec.masks[l]
+        n_t = int((~mask).sum())
+        Gt = np.where(mask, dtype(0), G)              # grads of the transformed dims' outputs
+        g_shift = Gt.sum(-1, keepdims=True)
+        g_ls = (Gt * v_in * e).sum(-1, keepdims=True) - dtype(n_t) / n
+        g_out = np.concatenate([g_shift, g_ls], -1)
+        lin = spec.layers[l]
+        lg = []
+        g = g_out
+        for j in reversed(range(len(lin))):
+            W = np.asarray(lin[j][0], dtype)
+            lg.append((acts[j].T @ g, g.sum(0)))
+            g = g @ W.T
+            if j > 0:
+                g = g * (pre[j - 1] > 0)
+        grads[l] = lg[::-1]
+        G = np.where(mask, G + g, Gt * e)             # d/d(input): pass-through dims also feed the MLP
+    return float(nll), grads
+
+
+def adam_reference(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """optax.adam update on flat float64 arrays (scale_by_adam + scale(-lr)); returns (params, m, v)."""
+    m = b1 * m + (1 - b1) * grads
+    v = b2 * v + (1 - b2) * grads * grads
+    mh = m / (1 - b1 ** step)
+    vh = v / (1 - b2 ** step)
+    return params - lr * mh / (np.sqrt(vh) + eps), m, v

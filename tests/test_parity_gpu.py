@@ -545,3 +545,79 @@ def test_rqs_general_path_register_kernel(nfa, monkeypatch, K, D, hidden, L, row
     x32, l32 = O.chain_inverse(spec, z, np.float32)
     assert_close(xb, xr, "general rqs inverse", 4 * np.abs(x32 - xr).max())
     assert_close(ldb, ldr, "general rqs inverse logdet", 4 * np.abs(l32 - ldr).max())
+
+
+# ------------------------------------------------------------------ backward pass / training step
+def _flat(layers):
+    return np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()])
+                           for layer in layers for W, b in layer])
+
+
+@pytest.mark.parametrize("L,parity,rows,density", [(8, 1, 4096, "banana"), (3, 0, 1000, "energy2"), (1, 1, 33, "gaussian_blobs"),
+                                                   (11, 1, 5000, "energy4")])
+def test_affine_nll_gradient(nfa, L, parity, rows, density):
+    """d NLL / d weights against the oracle's hand-derived float64 reverse-mode (itself checked against
+    finite differences in tests/test_oracle_kat.py).  Tolerance per tensor: 2e-4 of its largest entry."""
+    spec = O.make_affine_spec(L, final_std=0.03, first_parity=parity)
+    f = affine_flow(nfa, spec, parity)
+    x = O.make_inputs(density, rows, seed=L)
+    nll, grads = f.nll_grad(x)
+    rnll, rgrads = O.affine_nll_and_grad(spec, x)
+    assert abs(nll - rnll) <= 1e-5 * max(1.0, abs(rnll))
+    for l in range(L):
+        for j in range(3):
+            for which in (0, 1):
+                got, ref = grads[l][j][which], rgrads[l][j][which]
+                assert got.shape == ref.shape
+                scale = max(np.abs(ref).max(), 1e-6)
+                assert np.abs(got - ref).max() <= 2e-4 * scale, (l, j, which, np.abs(got - ref).max(), scale)
+    # the masked input's row of the first Linear gets exactly zero
+    for l in range(L):
+        masked_row = 0 if spec.masks[l][1] else 1
+        assert np.all(grads[l][0][0][masked_row] == 0)
+
+
+def test_affine_adam_training_steps(nfa):
+    """Five `update` steps (src/real_nvp_toy_densities.py:164-173) against optax.adam restated in float64."""
+    from normalizing_flows_amd import training
+    spec = O.make_affine_spec(4, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    opt = training.adam(1e-3)
+    ref_layers = [[(W.astype(np.float64), b.astype(np.float64)) for W, b in layer] for layer in spec.layers]
+    p = _flat(ref_layers)
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    losses = []
+    for step in range(1, 6):
+        x = O.make_inputs("banana", 2048, seed=100 + step)
+        loss = f.train_step(x, opt)
+        cur = O.FlowSpec("affine", 2, f.unpack_weights(p.astype(np.float64)), spec.masks)
+        rl, rg = O.affine_nll_and_grad(cur, x)
+        assert abs(loss - rl) <= 2e-5 * max(1.0, abs(rl)), (step, loss, rl)
+        p, m, v = O.adam_reference(p, _flat(rg), m, v, step, 1e-3)
+        losses.append(loss)
+    got = _flat(f.get_weights())
+    # Adam's first steps move every weight by ~lr regardless of gradient size, so compare to lr
+    assert np.abs(got - p).max() <= 0.05 * 5 * 1e-3, np.abs(got - p).max()
+    assert np.abs(got - _flat(spec.layers)).max() > 1e-3      # the weights did move
+    # the updated weights are what log_prob now uses
+    x = O.make_inputs("banana", 1000, seed=7)
+    new_spec = O.FlowSpec("affine", 2, f.get_weights(), spec.masks)
+    assert_close(f.log_prob(x), O.log_prob(new_spec, x), "log_prob after training")
+    # SGD step
+    g_before = f.nll_grad(x)[1]
+    w_before = _flat(f.get_weights())
+    f.train_step(x, training.sgd(0.01))
+    assert np.abs(_flat(f.get_weights()) - (w_before - 0.01 * _flat(g_before))).max() <= 1e-6
+
+
+def test_training_reduces_nll(nfa):
+    from normalizing_flows_amd import training
+    spec = O.make_affine_spec(8, final_std=0.0)            # the reference's zero-initialised flow
+    f = affine_flow(nfa, spec)
+    opt = training.adam(1e-3)
+    x_eval = O.make_inputs("banana", 8192, seed=999)
+    before = f.nll(x_eval)
+    for step in range(60):
+        f.train_step(O.make_inputs("banana", 4096, seed=step), opt, want_nll=False)
+    after = f.nll(x_eval)
+    assert after < before - 0.2, (before, after)
