@@ -22,6 +22,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace nf {
 namespace affine2d_bwd {
 
@@ -277,8 +279,10 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
     }
   }
 
-  // one partial gradient per wave
-  float* P = p.partials + ((size_t)blockIdx.x * 4 + wave) * kPartialFloats;
+  // one partial gradient per workgroup: the four waves lay theirs out in LDS (the weight image
+  // and the transpose scratch are dead by now), then they are added in wave order
+  __syncthreads();
+  float* P = lds + wave * kPartialFloats;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -301,35 +305,52 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
       }
     }
   const float t3s = half_sum(db3s), t3l = half_sum(db3l);
-  if (lane == 0) { P[pB3 + 0] = t3s; P[pB3 + 1] = t3l; }
+  if (lane == 0) { P[pB3 + 0] = t3s; P[pB3 + 1] = t3l; P[pB3 + 2] = 0.f; P[pB3 + 3] = 0.f; }
+  __syncthreads();
+  float* out = p.partials + (size_t)blockIdx.x * kPartialFloats;
+  for (int q = tid; q < kPartialFloats; q += 256)
+    out[q] = ((lds[q] + lds[kPartialFloats + q]) + lds[2 * kPartialFloats + q]) + lds[3 * kPartialFloats + q];
 }
 
-// grad[e] = scale[e] / rows_global * sum over waves of partial[w][map[e]], waves added in a fixed order
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ partials, int waves,
+// grad[e] = scale[e] / rows_global * sum over workgroups of partial[b][map[e]].  Fixed order: chunk c
+// adds workgroups c, c+4, c+8, ... (Kahan), then the four chunks are added in order.
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ partials, int nparts,
                                                      const int* __restrict__ map, const float* __restrict__ scale,
                                                      float* __restrict__ grad, float inv_rows) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kCanonFloats) return;
-  const int src = map[e];
-  float s = 0.f;
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int src = e < kCanonFloats ? map[e] : -1;
+  float s = 0.f, c = 0.f;
   if (src >= 0) {
-    float c = 0.f;  // Kahan: 1024 partials of very different magnitude
-    for (int w = 0; w < waves; ++w) {
-      const float y = partials[(size_t)w * kPartialFloats + src] - c;
-      const float t = s + y;
-      c = (t - s) - y;
-      s = t;
+    for (int w0 = chunk; w0 < nparts; w0 += 32) {
+      float y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int w = w0 + 4 * u;
+        y[u] = w < nparts ? partials[(size_t)w * kPartialFloats + src] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float yy = y[u] - c;
+        const float t = s + yy;
+        c = (t - s) - yy;
+        s = t;
+      }
     }
   }
-  grad[e] = s * scale[e] * inv_rows;
+  red[chunk][el] = s;
+  __syncthreads();
+  if (chunk == 0 && e < kCanonFloats)
+    grad[e] = (((red[0][el] + red[1][el]) + red[2][el]) + red[3][el]) * scale[e] * inv_rows;
 }
 
 int grid_blocks() { return 256; }
 
 int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream) {
+                 hipStream_t stream, int* out_parts) {
   static bool attr_set = false;
-  const size_t lds_bytes = (size_t)(kImageFloats + 4 * kWaveScratch) * sizeof(float);
+  const size_t lds_bytes = (size_t)std::max(kImageFloats + 4 * kWaveScratch, 4 * kPartialFloats) * sizeof(float);
   if (!attr_set) {
     NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -343,15 +364,18 @@ int launch_layer(const float* img, float* v, float* G, float* partials, long lon
   p.rows = rows;
   p.cond_dim = cond_dim;
   p.first = first;
-  hipLaunchKernelGGL(layer_kernel, dim3(grid_blocks()), dim3(256), lds_bytes, stream, p);
+  const long long tiles = (rows + 31) / 32;
+  const int grid = (int)std::min<long long>(grid_blocks(), std::max<long long>(1, (tiles + 3) / 4));
+  if (out_parts) *out_parts = grid;
+  hipLaunchKernelGGL(layer_kernel, dim3(grid), dim3(256), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
 
-int launch_gather(const float* partials, const int* map, const float* scale, float* grad, long long rows_global,
-                  hipStream_t stream) {
-  hipLaunchKernelGGL(gather_kernel, dim3((kCanonFloats + 255) / 256), dim3(256), 0, stream, partials,
-                     grid_blocks() * 4, map, scale, grad, 1.0f / (float)rows_global);
+int launch_gather(const float* partials, int nparts, const int* map, const float* scale, float* grad,
+                  long long rows_global, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_kernel, dim3((kCanonFloats + 63) / 64), dim3(256), 0, stream, partials, nparts, map, scale,
+                     grad, 1.0f / (float)rows_global);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

@@ -816,9 +816,10 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   // backward: the layer log_prob applied last (layer 0) first
   for (int l = 0; l < d.num_layers; ++l) {
     const int cond = (d.first_mask_parity + l) & 1;
+    int nparts = 0;
     NF_TRY(affine2d_bwd::launch_layer(t.d_bwd_img + (size_t)l * affine2d_bwd::kImageFloats, t.d_state_v, t.d_state_g,
-                                      t.d_partials, rows_local, cond, l == 0, f->stream));
-    NF_TRY(affine2d_bwd::launch_gather(t.d_partials, t.d_gmap[cond], t.d_gscale[cond],
+                                      t.d_partials, rows_local, cond, l == 0, f->stream, &nparts));
+    NF_TRY(affine2d_bwd::launch_gather(t.d_partials, nparts, t.d_gmap[cond], t.d_gscale[cond],
                                        t.d_grad + (size_t)l * affine2d_bwd::kCanonFloats, rows_global, f->stream));
   }
   if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));

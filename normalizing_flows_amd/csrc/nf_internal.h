@@ -96,9 +96,9 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
 void build_gather_map(int cond_dim, int* map /*[kCanonFloats]*/, float* scale);
 int grid_blocks();
 int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream);
-int launch_gather(const float* partials, const int* map, const float* scale, float* grad, long long rows_global,
-                  hipStream_t stream);
+                 hipStream_t stream, int* out_parts);
+int launch_gather(const float* partials, int nparts, const int* map, const float* scale, float* grad,
+                  long long rows_global, hipStream_t stream);
 }  // namespace affine2d_bwd
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 long long step, hipStream_t stream);

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from normalizing_flows_amd import _lib, flow  # noqa: E402
 from oracle import flows_np as O  # noqa: E402
 
-which = sys.argv[1:] or ["a", "b4k", "c", "d"]
+which = sys.argv[1:] or ["a", "b4k", "c", "d", "train"]
 
 
 def time_log_prob(f, xd, rows, steps=10, warm=2):
@@ -82,3 +82,28 @@ if "d" in which:   # configs[4]: MNIST shape, 6 layers, batch 2^16
                       "kernel": f.kernel_name, "ms": ms, "evals_per_s": rows / ms * 1e3,
                       "useful_TFLOPs": rows * 71.3e6 / ms / 1e9, "frac_f32_mfma_peak": rows * 71.3e6 / ms / 1e9 / 157.3,
                       "finite": bool(np.isfinite(lp).all()), "setup_s": time.time() - t0}))
+
+if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densities.py:164-173), 8 layers
+    from normalizing_flows_amd import training
+    spec = O.make_affine_spec(8, final_std=0.02)
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
+    f = flow.CouplingFlow(cfg, spec.layers)
+    opt = training.adam(1e-4)
+    for lg in (7, 12, 20):
+        rows = 1 << lg
+        xd = flow.DeviceArray.from_numpy(O.make_inputs("banana", rows))
+        for _ in range(3):
+            f.train_step(xd, opt, want_nll=False)
+        f.synchronize()
+        steps = 20
+        t0 = time.perf_counter()
+        f.timer_start()
+        for _ in range(steps):
+            f.train_step(xd, opt, want_nll=False)
+        ms = f.timer_stop() / steps
+        f.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        # forward 1x + backward 3x the 64x64 products (+ the small layers): 4 * 69,632 FLOP per sample
+        print(json.dumps({"config": f"train step (fwd + bwd + Adam) variant B L=8 banana batch=2^{lg}", "ms_stream": ms,
+                          "ms_wall": wall, "samples_per_s": rows / ms * 1e3,
+                          "TFLOPs_at_4x_forward": rows * 4 * 69632 / ms / 1e9}))
