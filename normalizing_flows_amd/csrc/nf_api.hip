@@ -433,10 +433,12 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
   NF_HIP(hipMemcpy(f->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   f->have_weights = true;
   if (f->train.ready) {  // a training state exists: restart it from the new weights
-    NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
     NF_HIP(hipMemset(f->train.d_m, 0, count * sizeof(float)));
     NF_HIP(hipMemset(f->train.d_v, 0, count * sizeof(float)));
     f->train.step = 0;
+  }
+  if (f->train.ready && f->path == PATH_AFFINE2D_H64) {
+    NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
     NF_TRY(launch_repack(f->train.d_canon, f->train.d_bsrc, f->train.d_bshift, f->train.d_bwd_img,
                          (size_t)d.num_layers * affine2d_bwd::kImageFloats, f->stream));
     NF_HIP(hipStreamSynchronize(f->stream));
@@ -732,13 +734,26 @@ static int upload(T** dst, const std::vector<T>& host) {
 }
 
 static int ensure_train(nf_flow* f, long long rows) {
-  if (f->path != PATH_AFFINE2D_H64) {
-    set_error("the backward pass is built for the fused masked-affine flow (D = 2, conditioner 2-64-64-2) only");
+  const bool split = f->path == PATH_SPLIT2D_SMALL && split2d::bwd_supported(f->desc.hidden[0]);
+  if (f->path != PATH_AFFINE2D_H64 && !split) {
+    set_error("the backward pass is built for the fused masked-affine flow (D = 2, conditioner 2-64-64-2) and the "
+              "split flow of src/real_nvp.py (D = 2, MLP 1-H-2, H = 4, 8, 16)");
     return NF_ERR_UNSUPPORTED;
   }
   nf_flow::Train& t = f->train;
   const nf_flow_desc& d = f->desc;
   const size_t n = f->weight_count;
+  if (!t.ready && split) {
+    // the split kernels read the canonical layout directly: d_wimg IS the weight vector
+    NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_m, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_v, n * sizeof(float)));
+    NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
+    NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_partials, (size_t)split2d::bwd_max_blocks() * split2d::layer_floats(d.hidden[0]) * sizeof(float)));
+    t.step = 0;
+    t.ready = true;
+  }
   if (!t.ready) {
     NF_HIP(hipMalloc(&t.d_canon, n * sizeof(float)));
     NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
@@ -798,7 +813,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
     io.rows = rows_local;
     io.layer_begin = 0;
     io.layer_end = d.num_layers;
-    direction_flags(NF_DIR_CHAIN_FORWARD, &io.descending, &io.inverse_op);
+    direction_flags(default_direction(f), &io.descending, &io.inverse_op);
     io.x = x_dev;
     io.y = t.d_state_v;
     io.block_sums = sums;
@@ -814,6 +829,15 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   f->tail_pending[slot] = true;
   f->ring_rows[slot] = rows_global;
   // backward: the layer log_prob applied last (layer 0) first
+  if (f->path == PATH_SPLIT2D_SMALL) {
+    const int H = d.hidden[0], per = split2d::layer_floats(H);
+    for (int l = 0; l < d.num_layers; ++l)
+      NF_TRY(split2d::launch_bwd_layer(f->d_wimg + (size_t)l * per, H, d.activation, t.d_state_v, t.d_state_g,
+                                       t.d_partials, t.d_grad + (size_t)l * per, rows_local, rows_global,
+                                       (l & 1) ^ d.first_mask_parity, l == 0, f->stream));
+    if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+    return NF_OK;
+  }
   for (int l = 0; l < d.num_layers; ++l) {
     const int cond = (d.first_mask_parity + l) & 1;
     int nparts = 0;
@@ -870,15 +894,18 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
   NF_TRY(stage_train_input(f, x, rows_local, mem, &x_dev));
   NF_TRY(enqueue_nll_grad(f, x_dev, rows_local, rows_global));
   t.step += 1;
+  float* canon = f->path == PATH_SPLIT2D_SMALL ? f->d_wimg : t.d_canon;
   if (opt->kind == NF_OPT_ADAM)
-    NF_TRY(launch_adam(t.d_canon, t.d_grad, t.d_m, t.d_v, f->weight_count, opt->learning_rate, opt->beta1, opt->beta2,
+    NF_TRY(launch_adam(canon, t.d_grad, t.d_m, t.d_v, f->weight_count, opt->learning_rate, opt->beta1, opt->beta2,
                        opt->eps, t.step, f->stream));
   else
-    NF_TRY(launch_sgd(t.d_canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream));
-  NF_TRY(launch_repack(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg,
-                       (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
-  NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
-                       (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    NF_TRY(launch_sgd(canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream));
+  if (f->path == PATH_AFFINE2D_H64) {
+    NF_TRY(launch_repack(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg,
+                         (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
+    NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
+                         (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+  }
   t.dirty = true;
   if (out_nll) {
     NF_TRY(nf_flow_synchronize(f));
@@ -893,7 +920,8 @@ int nf_flow_get_weights(nf_flow* f, float* packed, size_t count) {
   if (count != f->weight_count) { set_error("expected room for %zu weights, got %zu", f->weight_count, count); return NF_ERR_INVALID; }
   if (f->train.ready && f->train.dirty) {
     NF_TRY(nf_flow_synchronize(f));
-    NF_HIP(hipMemcpy(f->h_weights.data(), f->train.d_canon, count * sizeof(float), hipMemcpyDeviceToHost));
+    NF_HIP(hipMemcpy(f->h_weights.data(), f->path == PATH_SPLIT2D_SMALL ? f->d_wimg : f->train.d_canon,
+                     count * sizeof(float), hipMemcpyDeviceToHost));
     f->train.dirty = false;
   }
   memcpy(packed, f->h_weights.data(), count * sizeof(float));

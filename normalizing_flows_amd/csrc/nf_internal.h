@@ -130,6 +130,12 @@ __host__ __device__ inline int layer_floats(int H) { return 4 * H + 2; }
 int launch(const float* wimg, int H, int activation, int first_flip, const ChainIO& io,
            hipStream_t stream, int* out_grid);
 int max_grid();
+// training step (src/real_nvp.py:295-306): one backward launch per layer + its gradient gather
+bool bwd_supported(int H);
+int bwd_max_blocks();
+int launch_bwd_layer(const float* w_layer, int H, int activation, float* v, float* G, float* partials,
+                     float* grad_layer, long long rows, long long rows_global, int flip, int first,
+                     hipStream_t stream);
 }  // namespace split2d
 
 // ---- path 3: general path (GEMM chain + transform kernels), any D / widths / kind ---

@@ -171,6 +171,126 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
   return NF_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Backward of one split coupling layer (training step of src/real_nvp.py:295-306:
+// jax.value_and_grad(loss) + p - lr * g).  Like the masked flow's backward it stores no
+// activations: the walk starts from z and rebuilds each layer's input with forward_nvp while the
+// 12-FMA conditioner is recomputed.  One launch per layer, state (v, G) in HBM, the 4H+2
+// gradient accumulators of a thread in registers, fixed-order reduction to one partial per block.
+// loss_i = |z|^2/2 + log(2 pi) + sum(log_scale)  (log_prob = base - sum log_scale, :157-158)
+// ---------------------------------------------------------------------------
+template <int H, int LEAKY>
+__global__ __launch_bounds__(256) void bwd_layer_kernel(const float* __restrict__ w, float2* __restrict__ v,
+                                                        float2* __restrict__ G, float* __restrict__ partials,
+                                                        long long rows, int flip, int first) {
+  float dw0[H], db0[H], dw1s[H], dw1l[H];
+  float db1s = 0.f, db1l = 0.f;
+#pragma unroll
+  for (int k = 0; k < H; ++k) { dw0[k] = 0.f; db0[k] = 0.f; dw1s[k] = 0.f; dw1l[k] = 0.f; }
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    const float2 s = v[r];
+    const float2 g = first ? s : G[r];
+    const float c = flip ? s.y : s.x;      // conditioning half (unchanged by the layer)
+    const float x2 = flip ? s.x : s.y;     // the layer's OUTPUT on the transformed half
+    float Gc = flip ? g.y : g.x;
+    const float G2 = flip ? g.x : g.y;
+    float a[H], pre[H];
+    float shift = w[4 * H], ls = w[4 * H + 1];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      pre[k] = fmaf(c, w[k], w[H + k]);
+      a[k] = LEAKY ? fmaxf(pre[k], 0.01f * pre[k]) : fmaxf(pre[k], 0.f);
+      shift = fmaf(a[k], w[2 * H + 2 * k], shift);
+      ls = fmaf(a[k], w[2 * H + 2 * k + 1], ls);
+    }
+    const float einv = exp_f32(-ls);
+    const float y2 = fmaf(x2, exp_f32(ls), shift);   // the layer's input: forward_nvp (src/real_nvp.py:96)
+    const float g_s = -G2 * einv;                     // x2 = (y2 - shift) e^-ls
+    const float g_ls = fmaf(-G2, x2, 1.f);            // d x2 / d ls = -x2; +1 from the sum of log_scale
+    db1s += g_s;
+    db1l += g_ls;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      dw1s[k] = fmaf(a[k], g_s, dw1s[k]);
+      dw1l[k] = fmaf(a[k], g_ls, dw1l[k]);
+      const float ga = fmaf(w[2 * H + 2 * k], g_s, w[2 * H + 2 * k + 1] * g_ls);
+      const float gp = LEAKY ? (pre[k] >= 0.f ? ga : 0.01f * ga) : (pre[k] > 0.f ? ga : 0.f);
+      dw0[k] = fmaf(gp, c, dw0[k]);
+      db0[k] += gp;
+      Gc = fmaf(gp, w[k], Gc);
+    }
+    const float Gy2 = G2 * einv;
+    v[r] = flip ? make_float2(y2, c) : make_float2(c, y2);
+    G[r] = flip ? make_float2(Gy2, Gc) : make_float2(Gc, Gy2);
+  }
+  // block reduction in a fixed order: lanes (shuffle tree), then the four waves
+  __shared__ float red[4][4 * H + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto wsum = [](float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    return x;
+  };
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const float s0 = wsum(dw0[k]), s1 = wsum(db0[k]), s2 = wsum(dw1s[k]), s3 = wsum(dw1l[k]);
+    if (lane == 0) { red[wave][k] = s0; red[wave][H + k] = s1; red[wave][2 * H + 2 * k] = s2; red[wave][2 * H + 2 * k + 1] = s3; }
+  }
+  const float t0 = wsum(db1s), t1 = wsum(db1l);
+  if (lane == 0) { red[wave][4 * H] = t0; red[wave][4 * H + 1] = t1; }
+  __syncthreads();
+  if (threadIdx.x < 4 * H + 2)
+    partials[(size_t)blockIdx.x * (4 * H + 2) + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// grad[e] = (1/rows_global) * sum over blocks of partial[b][e], blocks added in order
+__global__ __launch_bounds__(64) void bwd_gather_kernel(const float* __restrict__ partials, int nparts, int n,
+                                                       float* __restrict__ grad, float inv_rows) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f, c = 0.f;
+  for (int b = 0; b < nparts; ++b) {
+    const float y = partials[(size_t)b * n + e] - c;
+    const float t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+  grad[e] = s * inv_rows;
+}
+
+int bwd_max_blocks() { return 512; }
+bool bwd_supported(int H) { return H == 4 || H == 8 || H == 16; }
+
+template <int H>
+static void launch_bwd_h(const float* w, float* v, float* G, float* partials, long long rows, int flip, int first,
+                         int leaky, int grid, hipStream_t stream) {
+  if (leaky)
+    hipLaunchKernelGGL((bwd_layer_kernel<H, 1>), dim3(grid), dim3(256), 0, stream, w, reinterpret_cast<float2*>(v),
+                       reinterpret_cast<float2*>(G), partials, rows, flip, first);
+  else
+    hipLaunchKernelGGL((bwd_layer_kernel<H, 0>), dim3(grid), dim3(256), 0, stream, w, reinterpret_cast<float2*>(v),
+                       reinterpret_cast<float2*>(G), partials, rows, flip, first);
+}
+
+int launch_bwd_layer(const float* w_layer, int H, int activation, float* v, float* G, float* partials, float* grad_layer,
+                     long long rows, long long rows_global, int flip, int first, hipStream_t stream) {
+  if (!bwd_supported(H)) { set_error("split2d backward is built for hidden width 4, 8, 16"); return NF_ERR_UNSUPPORTED; }
+  const long long want = (rows + 255) / 256;
+  const int grid = (int)(want < 1 ? 1 : (want > bwd_max_blocks() ? bwd_max_blocks() : want));
+  const int leaky = activation == NF_ACT_LEAKY_RELU;
+  if (H == 4) launch_bwd_h<4>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
+  else if (H == 8) launch_bwd_h<8>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
+  else launch_bwd_h<16>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
+  NF_HIP(hipGetLastError());
+  const int n = layer_floats(H);
+  hipLaunchKernelGGL(bwd_gather_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, partials, grid, n, grad_layer,
+                     1.0f / (float)rows_global);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 }  // namespace split2d
 
 // ---------------------------------------------------------------------------

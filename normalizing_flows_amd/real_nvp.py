@@ -159,3 +159,28 @@ def loss(params, fns_config, batch) -> float:
     for fn, _ in fns_config:
         _require_fn(fn)
     return _chain_for(params, [flip for _, flip in fns_config]).nll(batch)
+
+
+def value_and_grad_loss(params, fns_config, batch):
+    """jax.value_and_grad(loss)(params, batch) (src/real_nvp.py:297): (nll, grads shaped like params)."""
+    for fn, _ in fns_config:
+        _require_fn(fn)
+    flow = _chain_for(params, [flip for _, flip in fns_config])
+    nll, grads = flow.nll_grad(np.ascontiguousarray(batch, np.float32))
+    return nll, [[[W, b] for W, b in layer] for layer in grads]
+
+
+def sgd_update(params, fns_config, batch, learning_rate: float = 1e-2):
+    """src/real_nvp.py:295-306: `nll, grads = value_and_grad(loss)(params, batch);
+    params = tree_multimap(lambda p, g: p - learning_rate * g, params, grads)`; returns (nll, params).
+    The step runs on the device (nf_train_step); the returned params are new arrays."""
+    from . import training
+    for fn, _ in fns_config:
+        _require_fn(fn)
+    flips = [flip for _, flip in fns_config]
+    flow = _chain_for(params, flips)
+    nll = flow.train_step(np.ascontiguousarray(batch, np.float32), training.sgd(learning_rate))
+    new_params = [[[W, b] for W, b in layer] for layer in flow.get_weights()]
+    # the handle now holds the new weights: keep it for the next call on these arrays
+    _CACHE[(_signature(new_params), tuple(bool(f) for f in flips))] = (flow, [a for net in new_params for lin in net for a in lin])
+    return nll, new_params

@@ -652,3 +652,51 @@ def adam_reference(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     mh = m / (1 - b1 ** step)
     vh = v / (1 - b2 ** step)
     return params - lr * mh / (np.sqrt(vh) + eps), m, v
+
+
+def a_nll_and_grad(params, flips, y, dtype=np.float64):
+    """jax.value_and_grad(loss)(params, batch) of src/real_nvp.py:292-297 restated by hand (float64).
+
+    Returns (nll, grads) with grads[l][k] = [dW, db] like params.  leaky_relu'(x) = 1 for x >= 0."""
+    v = np.asarray(y, dtype)
+    n = v.shape[0]
+    d = v.shape[1] // 2
+    tape = []
+    total = np.zeros(n, dtype)
+    for l in reversed(range(len(params))):          # log_prob: last layer's inverse first
+        net, flip = params[l], flips[l]
+        y1, y2 = _a_split(v, flip)
+        acts, pres = [y1], []
+        a = y1
+        for W, b in net[:-1]:
+            z = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+            pres.append(z)
+            a = leaky_relu(z)
+            acts.append(a)
+        W, b = net[-1]
+        out = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+        shift, ls = out[:, :d], out[:, d:]
+        x2 = (y2 - shift) * np.exp(-ls)
+        total = total - ls.sum(-1)
+        tape.append((l, flip, acts, pres, ls, x2))
+        v = _a_join(y1, x2, flip)
+    nll = np.mean(0.5 * np.sum(v * v, -1) + 0.5 * v.shape[1] * math.log(2 * math.pi) - total)
+    grads = [None] * len(params)
+    G = v / n
+    for l, flip, acts, pres, ls, x2 in reversed(tape):
+        G1, G2 = _a_split(G, flip)
+        einv = np.exp(-ls)
+        g_shift = -G2 * einv
+        g_ls = -G2 * x2 + dtype(1.0) / n
+        g = np.concatenate([g_shift, g_ls], -1)
+        net = params[l]
+        lg = []
+        for j in reversed(range(len(net))):
+            W = np.asarray(net[j][0], dtype)
+            lg.append([acts[j].T @ g, g.sum(0)])
+            g = g @ W.T
+            if j > 0:
+                g = g * np.where(pres[j - 1] >= 0, dtype(1), dtype(LEAKY_SLOPE))
+        grads[l] = lg[::-1]
+        G = _a_join(G1 + g, G2 * einv, flip)
+    return float(nll), grads

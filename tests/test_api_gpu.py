@@ -285,3 +285,21 @@ def test_training_step_through_the_distrax_surface(distrax):
     spec1 = spec_of(layers, "affine", 2)
     assert abs(O.nll(spec1, valid) - after) <= 1e-5 * max(1.0, abs(after))
     assert np.abs(layers[0].conditioner.linears[-1][0]).max() > 0
+
+
+def test_real_nvp_py_training_loop(distrax):
+    """The __main__ loop of src/real_nvp.py:286-315 (sgd_update on batches of the chosen density)."""
+    from normalizing_flows_amd import densities, real_nvp as R
+    params, fns_config = R.init_nvp_chain(n=8)
+    rng = np.random.default_rng(5)
+    params = [[[(rng.standard_normal(W.shape) * 0.1).astype(np.float32), b] for W, b in net] for net in params]
+    flips = [flip for _, flip in fns_config]
+    valid = next(densities.make_dataset_energy_2(seed=231, batch_size=8192, num_batches=1))
+    first = R.loss(params, fns_config, valid)
+    nll0, grads = R.value_and_grad_loss(params, fns_config, valid)
+    rn, rg = O.a_nll_and_grad(params, flips, valid)
+    assert abs(nll0 - rn) <= 1e-5 * max(1.0, abs(rn))
+    assert np.abs(grads[7][1][0] - rg[7][1][0]).max() <= 2e-4 * np.abs(rg[7][1][0]).max()
+    for batch in densities.make_dataset_energy_2(seed=231, batch_size=128, num_batches=300):
+        nll, params = R.sgd_update(params, fns_config, batch, learning_rate=1e-2)
+    assert R.loss(params, fns_config, valid) < first - 0.05

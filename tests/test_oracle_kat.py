@@ -322,3 +322,26 @@ def test_gradient_restatement_against_finite_differences():
     p = np.array([1.0, -2.0, 3.0]); g = np.array([0.5, -4.0, 1e-3])
     p2, m, v = O.adam_reference(p, g, np.zeros(3), np.zeros(3), 1, 1e-2)
     assert np.allclose(p2, p - 1e-2 * np.sign(g), atol=1e-6)
+
+
+def test_variant_a_gradient_restatement_against_finite_differences():
+    params, flips = O.make_a_params(3)
+    rng = np.random.default_rng(1)
+    for net in params:
+        for j in range(2):
+            net[j][1] = (rng.standard_normal(net[j][1].shape) * 0.1).astype(np.float32)
+    y = O.make_inputs("energy2", 50)
+    nll, grads = O.a_nll_and_grad(params, flips, y)
+    assert abs(nll - O.a_nll(params, flips, y)) < 1e-12
+    for l in range(3):
+        for j in range(2):
+            for which in range(2):
+                arr = params[l][j][which]
+                for idx in np.ndindex(arr.shape):
+                    def f(val):
+                        p2 = [[[W.astype(np.float64).copy(), b.astype(np.float64).copy()] for W, b in net] for net in params]
+                        p2[l][j][which][idx] = val
+                        return O.a_nll(p2, flips, y)
+                    old, eps = float(arr[idx]), 1e-6
+                    fd = (f(old + eps) - f(old - eps)) / (2 * eps)
+                    assert abs(fd - grads[l][j][which][idx]) <= 1e-7 * max(1.0, abs(fd))
