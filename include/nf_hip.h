@@ -141,6 +141,17 @@ int nf_flow_set_weights(nf_flow* flow, const float* packed, size_t count);
 int nf_flow_kernel_name(const nf_flow* flow, char* buf, size_t buf_len);
 int nf_flow_synchronize(nf_flow* flow);
 
+/* Per-handle options (nothing in the reference corresponds: jax picks its matmul
+   precision globally).  Known names:
+     "hidden_matmul" = "f32" (default): the hidden 64x64 Linear on the exact-float32 MFMA;
+                     = "bf16x3": the same Linear as six bf16 MFMAs on a three-way bf16
+                       split of both operands (dropped terms <= 2^-24 relative, the size
+                       of float32's own product rounding).  About 2x the throughput;
+                       affine2d_h64_mfma handles only, NF_ERR_UNSUPPORTED elsewhere.
+   Applies to every later chain walk of the handle (log_prob, nll, sample, chain_apply,
+   the forward half of nf_nll_grad keeps float32). */
+int nf_flow_set_option(nf_flow* flow, const char* name, const char* value);
+
 /* ---- the hot path -------------------------------------------------------- */
 /* Replaces log_prob.apply -> distrax.Transformed.log_prob
    (src/real_nvp_toy_densities.py:113-123, src/maf_toy_densities.py:112-125,

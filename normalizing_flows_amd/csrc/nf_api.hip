@@ -123,6 +123,10 @@ struct nf_flow {
   bool have_weights = false;
   size_t weight_count = 0;
   float* d_wimg = nullptr;  // path-specific packed weights
+  // PATH_AFFINE2D_H64 with nf_flow_set_option("hidden_matmul", "bf16x3"): a second image, rebuilt
+  // lazily from the canonical weights whenever they changed
+  bool x3 = false, x3_stale = true;
+  float* d_wimg_x3 = nullptr;
   generic::Plan plan;       // PATH_GENERIC
   std::vector<float> h_weights;  // canonical weights as last set from the host
   // training state (PATH_AFFINE2D_H64; allocated on first use)
@@ -174,10 +178,37 @@ static void direction_flags(int direction, int* descending, int* inverse_op) {
   }
 }
 
+static int refresh_x3_image(nf_flow* f) {
+  const nf_flow_desc& d = f->desc;
+  std::vector<float> w(f->weight_count);
+  NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));
+  const size_t per_layer = f->weight_count / d.num_layers;
+  std::vector<float> img((size_t)d.num_layers * affine2d_x3::kLayerFloats);
+  for (int l = 0; l < d.num_layers; ++l) {
+    const float* W1 = w.data() + per_layer * l;
+    const float* b1 = W1 + 2 * 64;
+    const float* W2 = b1 + 64;
+    const float* b2 = W2 + 64 * 64;
+    const float* W3 = b2 + 64;
+    const float* b3 = W3 + 64 * 2;
+    affine2d_x3::pack_layer(W1, b1, W2, b2, W3, b3, (d.first_mask_parity + l) & 1,
+                            img.data() + (size_t)l * affine2d_x3::kLayerFloats);
+  }
+  NF_HIP(hipStreamSynchronize(f->stream));
+  if (!f->d_wimg_x3) NF_HIP(hipMalloc(&f->d_wimg_x3, img.size() * sizeof(float)));
+  NF_HIP(hipMemcpy(f->d_wimg_x3, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  f->x3_stale = false;
+  return NF_OK;
+}
+
 // Enqueue a chain walk on device pointers.  out_grid = number of block sums written.
 static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
   ChainIO io = io_in;
   io.base = f->desc.base;
+  if (f->path == PATH_AFFINE2D_H64 && f->x3) {
+    if (f->x3_stale) NF_TRY(refresh_x3_image(f));
+    return affine2d_x3::launch(f->d_wimg_x3, f->desc.first_mask_parity, io, f->stream, out_grid);
+  }
   if (f->path == PATH_SPLIT2D_SMALL) {
     return split2d::launch(f->d_wimg, f->desc.hidden[0], f->desc.activation,
                            f->desc.first_mask_parity, io, f->stream, out_grid);
@@ -361,6 +392,7 @@ void nf_flow_destroy(nf_flow* f) {
   }
   if (f->side) hipStreamDestroy(f->side);
   hipFree(f->d_wimg);
+  hipFree(f->d_wimg_x3);
   {
     nf_flow::Train& t = f->train;
     hipFree(t.d_canon); hipFree(t.d_grad); hipFree(t.d_m); hipFree(t.d_v); hipFree(t.d_bwd_img);
@@ -392,6 +424,7 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
   for (size_t j = 0; j < in.size(); ++j) per_layer += (size_t)in[j] * out[j] + out[j];
   f->h_weights.assign(packed, packed + count);
   f->train.dirty = false;
+  f->x3_stale = true;
   std::vector<float> img;
   if (f->path == PATH_AFFINE2D_H64) {
     img.resize((size_t)d.num_layers * affine2d::kLayerFloats);
@@ -450,6 +483,26 @@ int nf_flow_kernel_name(const nf_flow* f, char* buf, size_t buf_len) {
   if (!f || !buf || !buf_len) { set_error("bad argument"); return NF_ERR_INVALID; }
   snprintf(buf, buf_len, "%s", path_name(f->path));
   return NF_OK;
+}
+
+int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
+  if (!f || !name || !value) { set_error("bad argument"); return NF_ERR_INVALID; }
+  if (strcmp(name, "hidden_matmul") == 0) {
+    if (strcmp(value, "f32") == 0) { f->x3 = false; return NF_OK; }
+    if (strcmp(value, "bf16x3") == 0) {
+      if (f->path != PATH_AFFINE2D_H64) {
+        set_error("hidden_matmul=bf16x3 exists for the %s kernel only, this flow runs %s",
+                  path_name(PATH_AFFINE2D_H64), path_name(f->path));
+        return NF_ERR_UNSUPPORTED;
+      }
+      f->x3 = true;
+      return NF_OK;
+    }
+    set_error("hidden_matmul: unknown value '%s' (f32, bf16x3)", value);
+    return NF_ERR_INVALID;
+  }
+  set_error("unknown option '%s'", name);
+  return NF_ERR_INVALID;
 }
 
 int nf_flow_synchronize(nf_flow* f) {
@@ -907,6 +960,7 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
                          (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
   }
   t.dirty = true;
+  f->x3_stale = true;
   if (out_nll) {
     NF_TRY(nf_flow_synchronize(f));
     NF_TRY(nf_nll_result(f, 0, out_nll));

@@ -69,6 +69,21 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
 int max_grid();  // blocks the launch uses at most (= size of block_sums needed)
 }  // namespace affine2d
 
+// ---- path 1, optional "bf16x3" hidden matmul (nf_flow_set_option) ------------------------------
+namespace affine2d_x3 {
+// image of ONE layer (floats); streamed through an LDS double buffer
+constexpr int kA = 0;                   // [3 part][4 kstep16][2 mtile][64 lane][8] bf16: W2 * 2^64 split hi/mid/lo
+constexpr int kW1B1 = 3 * 4 * 2 * 64 * 8 / 2;  // 6144: [64 k][2] (w1, b1) * 2^-64
+constexpr int kB2 = kW1B1 + 128;        // accumulator order, as affine2d
+constexpr int kW3 = kB2 + 64;
+constexpr int kB3 = kW3 + 128;
+constexpr int kLayerFloats = kB3 + 4;   // 6468 floats = 25,872 B
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, float* image);
+int launch(const float* wimg, int first_mask_parity, const ChainIO& io, hipStream_t stream, int* out_grid);
+constexpr int kMaxGrid = 512;
+}  // namespace affine2d_x3
+
 // ---- backward of path 1 (training step) ---------------------------------
 namespace affine2d_bwd {
 // per-layer canonical weights: W1[2][64], b1[64], W2[64][64], b2[64], W3[64][2], b3[2]

@@ -186,6 +186,10 @@ class CouplingFlow:
     def synchronize(self) -> None:
         check(self._lib.nf_flow_synchronize(self._h))
 
+    def set_option(self, name: str, value: str) -> None:
+        """nf_flow_set_option: e.g. ("hidden_matmul", "bf16x3") for the split-bf16 hidden Linear."""
+        check(self._lib.nf_flow_set_option(self._h, name.encode(), value.encode()))
+
     # -- helpers -------------------------------------------------------------
     def _rows_of(self, x: ArrayLike) -> int:
         D = self.config.event_dim

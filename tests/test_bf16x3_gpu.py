@@ -1,0 +1,160 @@
+"""GPU parity of the optional "bf16x3" hidden matmul (nf_flow_set_option) against the CPU oracle.
+
+Same tolerance as tests/test_parity_gpu.py: |hip - oracle_f64| <= 1e-5 * max(1, |oracle_f64|).
+The mode must hold it wherever the exact-float32 kernel does; it is an alternative evaluation
+order of the same float32 arithmetic (split operands, float32 accumulate), not a precision level.
+"""
+import numpy as np
+import pytest
+
+from oracle import flows_np as O
+from test_parity_gpu import DENSITIES, affine_flow, assert_close, rqs_flow, split_flow
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nfa(nf_lib):
+    from normalizing_flows_amd import _lib, flow
+    _lib.require_device()
+    return flow
+
+
+def x3_flow(nfa, spec, parity=1):
+    f = affine_flow(nfa, spec, parity)
+    f.set_option("hidden_matmul", "bf16x3")
+    return f
+
+
+@pytest.mark.parametrize("density", DENSITIES)
+def test_x3_log_prob_l8(nfa, density):
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs(density, 4096)
+    ref = O.log_prob(spec, x)
+    got = f.log_prob(x)
+    assert_close(got, ref, f"bf16x3 log_prob {density}")
+    # and statistically no further from float64 than the float32 restatement is
+    # (measured: rms 1.9e-6 against 2.7e-6 for NumPy float32 and 1.8e-6 for the exact-float32 kernel)
+    e32 = O.log_prob(spec, x, np.float32).astype(np.float64) - ref
+    err = got.astype(np.float64) - ref
+    scale = np.maximum(1.0, np.abs(ref))
+    rms = lambda e: float(np.sqrt(np.mean((e / scale) ** 2)))
+    assert rms(err) <= max(2 * rms(e32), 2e-7)
+    assert (np.abs(err) / scale).max() <= max(2 * (np.abs(e32) / scale).max(), 2e-6)
+
+
+@pytest.mark.parametrize("L,parity", [(1, 1), (1, 0), (2, 1), (3, 0), (5, 1), (9, 1), (10, 1), (12, 0), (19, 1)])
+def test_x3_layer_counts_and_parity(nfa, L, parity):
+    spec = O.make_affine_spec(L, final_std=0.02, first_parity=parity)
+    f = x3_flow(nfa, spec, parity)
+    x = O.make_inputs("energy2", 1500)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"L={L} parity={parity}")
+
+
+@pytest.mark.parametrize("rows", [1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 4097, 70001, 300000, 1 << 20])
+def test_x3_ragged_rows(nfa, rows):
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs("gaussian_blobs", rows, seed=rows)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"rows={rows}")
+
+
+@pytest.mark.parametrize("tune", ["1,8", "2,8", "4,8", "1,16", "1,4", "2,4"])
+def test_x3_every_instantiation(nfa, monkeypatch, tune):
+    monkeypatch.setenv("NF_AFFINE2D_X3_TUNE", tune)
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs("banana", 1 << 19, seed=5)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"tune {tune}")
+    assert abs(f.nll(x) - O.nll(spec, x)) <= 1e-5
+
+
+def test_x3_identity_at_init(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.0)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs("banana", 2048)
+    y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    assert np.array_equal(y, x)
+    assert np.all(ld == 0)
+
+
+def test_x3_chain_directions_and_sampling(nfa):
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs("energy4", 3000)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    assert_close(z, zr, "chain forward y")
+    assert_close(ld, ldr, "chain forward logdet")
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr2 = O.chain_inverse(spec, z)
+    assert_close(xb, xr, "chain inverse x")
+    assert_close(ldb, ldr2, "chain inverse logdet")
+    assert np.abs(xb - x).max() <= 2e-5 * max(1, np.abs(x).max())
+    for direction in (_lib.DIR_FIRST_TO_LAST_FORWARD, _lib.DIR_LAST_TO_FIRST_INVERSE):
+        y2, ld2 = f.chain_apply(direction, x, layer_begin=2, layer_end=7)
+        g = affine_flow(nfa, spec)
+        y3, ld3 = g.chain_apply(direction, x, layer_begin=2, layer_end=7)
+        assert np.abs(y2 - y3).max() <= 1e-5 * max(1, np.abs(y3).max())
+        assert np.abs(ld2 - ld3).max() <= 1e-5
+
+
+def test_x3_option_switches_and_errors(nfa):
+    from normalizing_flows_amd._lib import NFError
+    spec = O.make_affine_spec(8, final_std=0.02)
+    x = O.make_inputs("banana", 5000)
+    f = affine_flow(nfa, spec)
+    lp_f32 = f.log_prob(x)
+    f.set_option("hidden_matmul", "bf16x3")
+    lp_x3 = f.log_prob(x)
+    f.set_option("hidden_matmul", "f32")
+    assert np.array_equal(f.log_prob(x), lp_f32)      # back on the exact kernel, bit for bit
+    assert not np.array_equal(lp_x3, lp_f32)            # and the option did select another kernel
+    d = np.abs(lp_x3.astype(np.float64) - lp_f32) / np.maximum(1.0, np.abs(lp_f32))
+    assert d.max() <= 4e-6          # the two modes agree to a few float32 ulps
+    assert (d == 0).mean() > 0.5    # and mostly bit for bit
+    with pytest.raises(NFError):
+        f.set_option("hidden_matmul", "fp8")
+    with pytest.raises(NFError):
+        f.set_option("no_such_option", "1")
+    # flows on other kernels refuse the mode instead of ignoring it
+    g = split_flow(nfa, O.make_a_params(4)[0])
+    with pytest.raises(NFError):
+        g.set_option("hidden_matmul", "bf16x3")
+    r = rqs_flow(nfa, O.make_rqs_spec(2, final_std=0.05))
+    with pytest.raises(NFError):
+        r.set_option("hidden_matmul", "bf16x3")
+
+
+def test_x3_follows_weight_updates(nfa):
+    """set_weights and nf_train_step both invalidate the split image."""
+    from normalizing_flows_amd import training
+    spec_a = O.make_affine_spec(4, final_std=0.02)
+    spec_b = O.make_affine_spec(4, final_std=0.02, seed=99)
+    x = O.make_inputs("banana", 4096)
+    f = x3_flow(nfa, spec_a)
+    assert_close(f.log_prob(x), O.log_prob(spec_a, x), "before")
+    f.set_weights(spec_b.layers)
+    assert_close(f.log_prob(x), O.log_prob(spec_b, x), "after set_weights")
+    f.train_step(x, training.adam(1e-3))
+    spec_c = O.FlowSpec("affine", 2, f.get_weights(), spec_b.masks, "normal")
+    assert_close(f.log_prob(x), O.log_prob(spec_c, x), "after a training step")
+
+
+def test_x3_full_size_properties(nfa):
+    """BASELINE.json configs[1] batch (2^20): invertibility and the additive log-det."""
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = x3_flow(nfa, spec)
+    x = O.make_inputs("banana", 1 << 20, seed=11)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    assert np.abs(xb - x).max() <= 5e-5 * max(1, np.abs(x).max())
+    assert np.abs(ld + ldb).max() <= 2e-5
+    lp = f.log_prob(x)
+    base = -0.5 * (z.astype(np.float64) ** 2).sum(-1) - np.log(2 * np.pi)
+    assert np.abs(lp - (base + ld)).max() <= 1e-5 * max(1, np.abs(lp).max())
+    assert abs(f.nll(x) + float(np.mean(lp.astype(np.float64)))) <= 1e-6
