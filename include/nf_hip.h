@@ -146,8 +146,10 @@ int nf_flow_synchronize(nf_flow* flow);
      "hidden_matmul" = "f32" (default): the hidden 64x64 Linear on the exact-float32 MFMA;
                      = "bf16x3": the same Linear as six bf16 MFMAs on a three-way bf16
                        split of both operands (dropped terms <= 2^-24 relative, the size
-                       of float32's own product rounding).  About 2x the throughput;
-                       affine2d_h64_mfma handles only, NF_ERR_UNSUPPORTED elsewhere.
+                       of float32's own product rounding).  About 1.8x the throughput.
+                       Handles on the affine2d_h64_mfma kernel (its 64x64 Linear) and on
+                       the general path (every Linear with K >= 32 and N >= 64);
+                       NF_ERR_UNSUPPORTED on the other fused kernels.
    Applies to every later chain walk of the handle (log_prob, nll, sample, chain_apply,
    the forward half of nf_nll_grad keeps float32). */
 int nf_flow_set_option(nf_flow* flow, const char* name, const char* value);

@@ -488,18 +488,20 @@ int nf_flow_kernel_name(const nf_flow* f, char* buf, size_t buf_len) {
 int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
   if (!f || !name || !value) { set_error("bad argument"); return NF_ERR_INVALID; }
   if (strcmp(name, "hidden_matmul") == 0) {
-    if (strcmp(value, "f32") == 0) { f->x3 = false; return NF_OK; }
-    if (strcmp(value, "bf16x3") == 0) {
-      if (f->path != PATH_AFFINE2D_H64) {
-        set_error("hidden_matmul=bf16x3 exists for the %s kernel only, this flow runs %s",
-                  path_name(PATH_AFFINE2D_H64), path_name(f->path));
-        return NF_ERR_UNSUPPORTED;
-      }
-      f->x3 = true;
-      return NF_OK;
+    const bool on = strcmp(value, "bf16x3") == 0;
+    if (!on && strcmp(value, "f32") != 0) {
+      set_error("hidden_matmul: unknown value '%s' (f32, bf16x3)", value);
+      return NF_ERR_INVALID;
     }
-    set_error("hidden_matmul: unknown value '%s' (f32, bf16x3)", value);
-    return NF_ERR_INVALID;
+    if (f->path == PATH_AFFINE2D_H64) { f->x3 = on; return NF_OK; }
+    if (f->path == PATH_GENERIC) {
+      NF_HIP(hipStreamSynchronize(f->stream));
+      return f->plan.set_x3(on);
+    }
+    if (!on) return NF_OK;
+    set_error("hidden_matmul=bf16x3 exists for the %s and %s kernels, this flow runs %s",
+              path_name(PATH_AFFINE2D_H64), path_name(PATH_GENERIC), path_name(f->path));
+    return NF_ERR_UNSUPPORTED;
   }
   set_error("unknown option '%s'", name);
   return NF_ERR_INVALID;

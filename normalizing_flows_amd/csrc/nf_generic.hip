@@ -795,11 +795,34 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   }
   NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
   NF_HIP(hipMemcpy(d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  host_weights.swap(host);
+  if (x3) return set_x3(true);  // new weights under an option that was already on
+  return NF_OK;
+}
+
+// Build (or drop) the split-bf16 weight images of every Linear wide enough for gemm_x3_kernel.
+int Plan::set_x3(bool on) {
+  if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }
+  x3 = on;
+  if (!on || linears.empty()) return NF_OK;
+  size_t total = 0;
+  for (Linear& L : linears) {
+    L.x3_off = total;
+    if (L.N >= 64 && L.K >= 32) total += x3_image_halfwords(L.K, L.N);
+  }
+  if (total == 0) return NF_OK;
+  std::vector<unsigned short> img(total);
+  for (const Linear& L : linears)
+    if (L.N >= 64 && L.K >= 32) pack_w_x3(host_weights.data() + L.w_off, L.K, L.N, img.data() + L.x3_off);
+  NF_HIP(hipMalloc(&d_wx3, total * sizeof(unsigned short)));
+  NF_HIP(hipMemcpy(d_wx3, img.data(), total * sizeof(unsigned short), hipMemcpyHostToDevice));
   return NF_OK;
 }
 
 void Plan::release() {
   if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
+  if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }
+  host_weights.clear();
   if (d_scratch) { hipFree(d_scratch); d_scratch = nullptr; }
   scratch_rows = 0;
   linears.clear();
@@ -850,8 +873,12 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
-        NF_TRY(launch_gemm(a, lda, d_weights + L.w_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
-                           j == nlin - 1 ? 0 : act, stream));
+        if (x3 && d_wx3 && gemm_x3_applicable(a, lda, L.N, L.K))
+          NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
+                                j == nlin - 1 ? 0 : act, stream));
+        else
+          NF_TRY(launch_gemm(a, lda, d_weights + L.w_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
+                             j == nlin - 1 ? 0 : act, stream));
         a = dst;
         lda = L.N;
       }

@@ -158,6 +158,7 @@ namespace generic {
 struct Linear {
   int K = 0, N = 0;           // y[., N] = x[., K] @ W + b (after host-side pruning)
   size_t w_off = 0, b_off = 0;  // offsets into d_weights, floats
+  size_t x3_off = 0;            // offset into d_wx3 (bf16 units); valid when Plan::x3
 };
 struct Plan {
   nf_flow_desc desc;
@@ -167,12 +168,22 @@ struct Plan {
   long long scratch_rows = 0;
   int max_width = 0;
   int act_width = 0, param_width = 0;  // widest hidden layer / widest conditioner output
+  // optional "bf16x3" matmul (nf_gemm_x3.hip): split weight images, built on first use
+  bool x3 = false;
+  unsigned short* d_wx3 = nullptr;
+  std::vector<float> host_weights;  // what d_weights holds (after masking / pruning)
+  int set_x3(bool on);
   int build(const nf_flow_desc& d, const float* packed);
   void release();
   int ensure_scratch(long long rows);
   // y [rows, D] and ld [rows] hold the chain's input state and are updated in place
   int walk(float* y, float* ld, const ChainIO& io, hipStream_t stream);
 };
+size_t x3_image_halfwords(int K, int N);
+void pack_w_x3(const float* W /*[K][N]*/, int K, int N, unsigned short* image);
+bool gemm_x3_applicable(const float* A, int lda, int N, int K);
+int launch_gemm_x3(const float* A, int lda, const unsigned short* wimg, const float* bias, float* Cm, int ldc,
+                   int M, int N, int K, int act, hipStream_t stream);
 int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,
                          int D, int base, hipStream_t stream, int* out_grid);
 int launch_base_sample(float* out, long long rows, int D, int base, unsigned long long seed, hipStream_t stream);

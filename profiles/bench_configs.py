@@ -49,9 +49,11 @@ if "b4k" in which:  # configs[0]: 4 layers, banana, batch 4096 (latency-bound on
     f = flow.CouplingFlow(cfg, spec.layers)
     x = O.make_inputs("banana", 4096)
     xd = flow.DeviceArray.from_numpy(x)
-    ms, _ = time_log_prob(f, xd, 4096, steps=200, warm=20)
-    print(json.dumps({"config": "variant B L=4 banana batch=4096 (configs[0])", "kernel": f.kernel_name, "ms": ms,
-                      "evals_per_s": 4096 / ms * 1e3}))
+    for mode in ("f32", "bf16x3"):
+        f.set_option("hidden_matmul", mode)
+        ms, _ = time_log_prob(f, xd, 4096, steps=200, warm=20)
+        print(json.dumps({"config": "variant B L=4 banana batch=4096 (configs[0])", "hidden_matmul": mode,
+                          "kernel": f.kernel_name, "ms": ms, "evals_per_s": 4096 / ms * 1e3}))
 
 if "c" in which:   # configs[2]: spline coupling, 8 layers, K=12, [-8,8], gaussian_blobs, batch 2^20
     spec = O.make_rqs_spec(8, final_std=0.05)
@@ -76,12 +78,20 @@ if "d" in which:   # configs[4]: MNIST shape, 6 layers, batch 2^16
     rows = 1 << 16
     x = O.make_inputs("mnist_like", rows)
     xd = flow.DeviceArray.from_numpy(x)
-    ms, out = time_log_prob(f, xd, rows, steps=2, warm=1)
-    lp = out.to_numpy()
-    print(json.dumps({"config": "variant D (MNIST 784-D, MLP 512x3, RQS K=8) L=6 batch=2^16 (configs[4])",
-                      "kernel": f.kernel_name, "ms": ms, "evals_per_s": rows / ms * 1e3,
-                      "useful_TFLOPs": rows * 71.3e6 / ms / 1e9, "frac_f32_mfma_peak": rows * 71.3e6 / ms / 1e9 / 157.3,
-                      "finite": bool(np.isfinite(lp).all()), "setup_s": time.time() - t0}))
+    lp32 = None
+    for mode in ("f32", "bf16x3"):
+        f.set_option("hidden_matmul", mode)
+        ms, out = time_log_prob(f, xd, rows, steps=2, warm=1)
+        lp = out.to_numpy()
+        if lp32 is None:
+            lp32 = lp
+        print(json.dumps({"config": "variant D (MNIST 784-D, MLP 512x3, RQS K=8) L=6 batch=2^16 (configs[4])",
+                          "hidden_matmul": mode, "kernel": f.kernel_name, "ms": ms, "evals_per_s": rows / ms * 1e3,
+                          "useful_TFLOPs": rows * 71.3e6 / ms / 1e9,
+                          "frac_f32_mfma_peak": rows * 71.3e6 / ms / 1e9 / 157.3,
+                          "finite": bool(np.isfinite(lp).all()),
+                          "max_rel_diff_to_f32_mode": float(np.max(np.abs(lp - lp32) / np.maximum(1, np.abs(lp32)))),
+                          "setup_s": time.time() - t0}), flush=True)
 
 if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densities.py:164-173), 8 layers
     from normalizing_flows_amd import training

@@ -125,8 +125,10 @@ def test_x3_option_switches_and_errors(nfa):
     with pytest.raises(NFError):
         g.set_option("hidden_matmul", "bf16x3")
     r = rqs_flow(nfa, O.make_rqs_spec(2, final_std=0.05))
+    assert r.kernel_name != "generic_gemm"
     with pytest.raises(NFError):
         r.set_option("hidden_matmul", "bf16x3")
+    r.set_option("hidden_matmul", "f32")   # the default is accepted everywhere
 
 
 def test_x3_follows_weight_updates(nfa):
@@ -158,3 +160,76 @@ def test_x3_full_size_properties(nfa):
     base = -0.5 * (z.astype(np.float64) ** 2).sum(-1) - np.log(2 * np.pi)
     assert np.abs(lp - (base + ld)).max() <= 1e-5 * max(1, np.abs(lp).max())
     assert abs(f.nll(x) + float(np.mean(lp.astype(np.float64)))) <= 1e-6
+
+
+# ------------------------------------------------------------------ general path (nf_gemm_x3.hip)
+@pytest.mark.parametrize("D,hidden,L,parity", [(2, (64, 64, 64), 2, 1), (4, (64, 64), 4, 1), (40, (128, 96), 3, 0),
+                                               (64, (100, 260), 2, 1), (36, (64,), 3, 1)])
+def test_x3_generic_affine(nfa, D, hidden, L, parity):
+    """Every Linear with K >= 32, N >= 64 (multiples of 4) runs the split-bf16 GEMM, the others the
+    float32 one; the chain must hold the same tolerance either way."""
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(L, event_size=D, hidden=hidden, final_std=0.03, first_parity=parity)
+    f = affine_flow(nfa, spec, parity)
+    assert f.kernel_name == "generic_gemm"
+    x = np.random.default_rng(D * 100 + L).standard_normal((3001, D)).astype(np.float32) * 1.5
+    lp32 = f.log_prob(x)
+    f.set_option("hidden_matmul", "bf16x3")
+    lp = f.log_prob(x)
+    ref = O.log_prob(spec, x)
+    assert_close(lp, ref, "generic bf16x3 log_prob")
+    assert not np.array_equal(lp, lp32)  # the option did switch kernels
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    assert_close(z, zr, "generic bf16x3 z")
+    assert_close(ld, ldr, "generic bf16x3 logdet")
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr2 = O.chain_inverse(spec, z)
+    assert_close(xb, xr, "generic bf16x3 inverse")
+    assert_close(ldb, ldr2, "generic bf16x3 inverse logdet")
+    f.set_option("hidden_matmul", "f32")
+    assert np.array_equal(f.log_prob(x), lp32)
+    # new weights under the option
+    spec2 = O.make_affine_spec(L, event_size=D, hidden=hidden, final_std=0.03, first_parity=parity, seed=77)
+    f.set_option("hidden_matmul", "bf16x3")
+    f.set_weights(spec2.layers)
+    assert_close(f.log_prob(x), O.log_prob(spec2, x), "generic bf16x3 after set_weights")
+
+
+@pytest.mark.parametrize("rows", [1, 127, 128, 129, 1000])
+def test_x3_generic_ragged_rows(nfa, rows):
+    spec = O.make_affine_spec(3, event_size=8, hidden=(96, 160), final_std=0.03)
+    f = affine_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    x = np.random.default_rng(rows).standard_normal((rows, 8)).astype(np.float32)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), f"rows={rows}")
+
+
+def test_x3_generic_rqs(nfa):
+    spec = O.make_rqs_spec(3, event_size=6, hidden=(64, 64), num_bins=8, range_min=-4.0, range_max=4.0,
+                           final_std=0.1, first_parity=0)
+    f = rqs_flow(nfa, spec, 0)
+    assert f.kernel_name == "generic_gemm"
+    f.set_option("hidden_matmul", "bf16x3")
+    x = np.random.default_rng(6).standard_normal((1500, 6)).astype(np.float32) * 2.0
+    assert_close(f.log_prob(x), O.log_prob(spec, x), "rqs D=6 bf16x3")
+
+
+def test_x3_mnist_shape(nfa):
+    """BASELINE.json configs[4] shapes under the option; the two statements of
+    tests/test_parity_gpu.py::test_rqs_mnist_shape_config5."""
+    x = O.make_inputs("mnist_like", 96)
+    spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0,
+                           range_max=1.0, base="uniform01", final_std=0.2)
+    f = rqs_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    ref = O.log_prob(spec, x)
+    assert_close(f.log_prob(x), ref, "mnist-shaped rqs bf16x3 (i)")
+    spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0,
+                           range_max=1.0, base="uniform01", final_std=0.02)
+    f = rqs_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32).astype(np.float64) - ref).max()
+    got = f.log_prob(x)
+    assert np.abs(got - ref).max() <= 2 * e32 + 1e-6, (np.abs(got - ref).max(), e32)
