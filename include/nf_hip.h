@@ -147,12 +147,16 @@ int nf_flow_synchronize(nf_flow* flow);
                      = "bf16x3": the same Linear as six bf16 MFMAs on a three-way bf16
                        split of both operands (dropped terms <= 2^-24 relative, the size
                        of float32's own product rounding).  About 1.8x the throughput.
-                       Handles on the affine2d_h64_mfma kernel (its 64x64 Linear) and on
-                       the general path (every Linear with K >= 32 and N >= 64);
-                       NF_ERR_UNSUPPORTED on the other fused kernels.
+                       Handles on the affine2d_h64_mfma kernel (its 64x64 Linear), the
+                       fused spline kernel (both of its Linears) and the general path
+                       (every Linear with K >= 32 and N >= 64); NF_ERR_UNSUPPORTED on the
+                       split2d kernel, which has no MFMA.
    Applies to every later chain walk of the handle (log_prob, nll, sample, chain_apply,
    the forward half of nf_nll_grad keeps float32). */
 int nf_flow_set_option(nf_flow* flow, const char* name, const char* value);
+int nf_flow_get_option(const nf_flow* flow, const char* name, char* buf, size_t buf_len);
+/* The environment variable NF_HIDDEN_MATMUL=bf16x3 makes that value the default of every
+   handle created afterwards on a kernel that has the mode. */
 
 /* ---- the hot path -------------------------------------------------------- */
 /* Replaces log_prob.apply -> distrax.Transformed.log_prob

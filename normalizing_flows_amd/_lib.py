@@ -89,6 +89,7 @@ PROTOTYPES = {
     "nf_flow_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "nf_flow_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "nf_flow_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "nf_flow_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "nf_flow_synchronize": (C.c_int, [C.c_void_p]),
     "nf_log_prob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_chain_log_prob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),

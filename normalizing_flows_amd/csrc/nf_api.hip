@@ -183,16 +183,20 @@ static int refresh_x3_image(nf_flow* f) {
   std::vector<float> w(f->weight_count);
   NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));
   const size_t per_layer = f->weight_count / d.num_layers;
-  std::vector<float> img((size_t)d.num_layers * affine2d_x3::kLayerFloats);
+  const bool rqs = f->path == PATH_RQS2D_H64;
+  const size_t image_floats = rqs ? rqs2d_x3::kLayerFloats : affine2d_x3::kLayerFloats;
+  const int P = 3 * d.rqs_bins + 1;
+  std::vector<float> img((size_t)d.num_layers * image_floats);
   for (int l = 0; l < d.num_layers; ++l) {
     const float* W1 = w.data() + per_layer * l;
     const float* b1 = W1 + 2 * 64;
     const float* W2 = b1 + 64;
     const float* b2 = W2 + 64 * 64;
     const float* W3 = b2 + 64;
-    const float* b3 = W3 + 64 * 2;
-    affine2d_x3::pack_layer(W1, b1, W2, b2, W3, b3, (d.first_mask_parity + l) & 1,
-                            img.data() + (size_t)l * affine2d_x3::kLayerFloats);
+    const float* b3 = W3 + 64 * (rqs ? 2 * P : 2);
+    const int cond_dim = (d.first_mask_parity + l) & 1;
+    if (rqs) rqs2d_x3::pack_layer(W1, b1, W2, b2, W3, b3, cond_dim, d.rqs_bins, img.data() + l * image_floats);
+    else affine2d_x3::pack_layer(W1, b1, W2, b2, W3, b3, cond_dim, img.data() + l * image_floats);
   }
   NF_HIP(hipStreamSynchronize(f->stream));
   if (!f->d_wimg_x3) NF_HIP(hipMalloc(&f->d_wimg_x3, img.size() * sizeof(float)));
@@ -205,8 +209,9 @@ static int refresh_x3_image(nf_flow* f) {
 static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
   ChainIO io = io_in;
   io.base = f->desc.base;
-  if (f->path == PATH_AFFINE2D_H64 && f->x3) {
+  if (f->x3 && (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64)) {
     if (f->x3_stale) NF_TRY(refresh_x3_image(f));
+    if (f->path == PATH_RQS2D_H64) return rqs2d_x3::launch(f->d_wimg_x3, f->desc, io, f->stream, out_grid);
     return affine2d_x3::launch(f->d_wimg_x3, f->desc.first_mask_parity, io, f->stream, out_grid);
   }
   if (f->path == PATH_SPLIT2D_SMALL) {
@@ -356,6 +361,14 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
     f->path = PATH_RQS2D_H64;
   else
     f->path = PATH_GENERIC;
+  // NF_HIDDEN_MATMUL=bf16x3: process-wide default of the "hidden_matmul" option for the kernels
+  // that have the mode (lets a whole test suite or script run under it unchanged)
+  if (const char* e = getenv("NF_HIDDEN_MATMUL")) {
+    if (strcmp(e, "bf16x3") == 0) {
+      if (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64) f->x3 = true;
+      else if (f->path == PATH_GENERIC) f->plan.x3 = true;
+    }
+  }
   int s = NF_OK;
   do {
     if (hipGetDevice(&f->device) != hipSuccess) { s = hip_fail(hipGetLastError(), "hipGetDevice", __FILE__, __LINE__); break; }
@@ -493,15 +506,26 @@ int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
       set_error("hidden_matmul: unknown value '%s' (f32, bf16x3)", value);
       return NF_ERR_INVALID;
     }
-    if (f->path == PATH_AFFINE2D_H64) { f->x3 = on; return NF_OK; }
+    if (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64) { f->x3 = on; return NF_OK; }
     if (f->path == PATH_GENERIC) {
       NF_HIP(hipStreamSynchronize(f->stream));
       return f->plan.set_x3(on);
     }
     if (!on) return NF_OK;
-    set_error("hidden_matmul=bf16x3 exists for the %s and %s kernels, this flow runs %s",
-              path_name(PATH_AFFINE2D_H64), path_name(PATH_GENERIC), path_name(f->path));
+    set_error("hidden_matmul=bf16x3 exists for the MFMA kernels (%s, %s, %s), this flow runs %s",
+              path_name(PATH_AFFINE2D_H64), path_name(PATH_RQS2D_H64), path_name(PATH_GENERIC), path_name(f->path));
     return NF_ERR_UNSUPPORTED;
+  }
+  set_error("unknown option '%s'", name);
+  return NF_ERR_INVALID;
+}
+
+int nf_flow_get_option(const nf_flow* f, const char* name, char* buf, size_t buf_len) {
+  if (!f || !name || !buf || !buf_len) { set_error("bad argument"); return NF_ERR_INVALID; }
+  if (strcmp(name, "hidden_matmul") == 0) {
+    const bool on = f->path == PATH_GENERIC ? f->plan.x3 : f->x3;
+    snprintf(buf, buf_len, "%s", on ? "bf16x3" : "f32");
+    return NF_OK;
   }
   set_error("unknown option '%s'", name);
   return NF_ERR_INVALID;

@@ -137,6 +137,19 @@ int max_grid();
 bool supported_bins(int K);
 }  // namespace rqs2d
 
+// ---- path 1b, optional "bf16x3" matmul: both MFMA passes on split-bf16 operands ----------------
+namespace rqs2d_x3 {
+constexpr int kA2 = 0;                  // [3 part][4 k16][2 mtile][64 lane][8] bf16   W2 * 2^64
+constexpr int kA3 = 6144;               // same shape: last Linear, k in accumulator order
+constexpr int kW1B1 = 12288;            // [64 k][2] (w1, b1) * 2^-64
+constexpr int kB2 = kW1B1 + 128;
+constexpr int kB3 = kB2 + 64;
+constexpr int kLayerFloats = kB3 + 64;  // 12,544 floats = 50,176 B
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                const float* b3, int cond_dim, int K, float* image);
+int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStream_t stream, int* out_grid);
+}  // namespace rqs2d_x3
+
 // ---- path 2: split-halves affine coupling (variant A), D = 2, MLP 1 -> H -> 2 ----
 namespace split2d {
 constexpr int kMaxHidden = 64;

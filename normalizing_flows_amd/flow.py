@@ -190,6 +190,11 @@ class CouplingFlow:
         """nf_flow_set_option: e.g. ("hidden_matmul", "bf16x3") for the split-bf16 hidden Linear."""
         check(self._lib.nf_flow_set_option(self._h, name.encode(), value.encode()))
 
+    def get_option(self, name: str) -> str:
+        buf = C.create_string_buffer(64)
+        check(self._lib.nf_flow_get_option(self._h, name.encode(), buf, 64))
+        return buf.value.decode()
+
     # -- helpers -------------------------------------------------------------
     def _rows_of(self, x: ArrayLike) -> int:
         D = self.config.event_dim

@@ -63,10 +63,14 @@ if "c" in which:   # configs[2]: spline coupling, 8 layers, K=12, [-8,8], gaussi
     rows = 1 << 20
     x = O.make_inputs("gaussian_blobs", rows)
     xd = flow.DeviceArray.from_numpy(x)
-    ms, _ = time_log_prob(f, xd, rows, steps=5)
-    print(json.dumps({"config": "variant C (RQS K=12) L=8 gaussian_blobs batch=2^20 (configs[2])", "kernel": f.kernel_name,
-                      "ms": ms, "evals_per_s": rows / ms * 1e3, "useful_TFLOPs": rows * 105472 / ms / 1e9,
-                      "frac_f32_mfma_peak": rows * 105472 / ms / 1e9 / 157.3}))
+    for mode in ("f32", "bf16x3"):
+        f.set_option("hidden_matmul", mode)
+        ms, _ = time_log_prob(f, xd, rows, steps=5)
+        print(json.dumps({"config": "variant C (RQS K=12) L=8 gaussian_blobs batch=2^20 (configs[2])",
+                          "hidden_matmul": mode, "tune": os.environ.get("NF_RQS2D_X3_TUNE", "default"),
+                          "kernel": f.kernel_name, "ms": ms, "evals_per_s": rows / ms * 1e3,
+                          "useful_TFLOPs": rows * 105472 / ms / 1e9,
+                          "frac_f32_mfma_peak": rows * 105472 / ms / 1e9 / 157.3}), flush=True)
 
 if "d" in which:   # configs[4]: MNIST shape, 6 layers, batch 2^16
     t0 = time.time()

@@ -124,11 +124,7 @@ def test_x3_option_switches_and_errors(nfa):
     g = split_flow(nfa, O.make_a_params(4)[0])
     with pytest.raises(NFError):
         g.set_option("hidden_matmul", "bf16x3")
-    r = rqs_flow(nfa, O.make_rqs_spec(2, final_std=0.05))
-    assert r.kernel_name != "generic_gemm"
-    with pytest.raises(NFError):
-        r.set_option("hidden_matmul", "bf16x3")
-    r.set_option("hidden_matmul", "f32")   # the default is accepted everywhere
+    g.set_option("hidden_matmul", "f32")   # the default is accepted everywhere
 
 
 def test_x3_follows_weight_updates(nfa):
@@ -233,3 +229,64 @@ def test_x3_mnist_shape(nfa):
     e32 = np.abs(O.log_prob(spec, x, np.float32).astype(np.float64) - ref).max()
     got = f.log_prob(x)
     assert np.abs(got - ref).max() <= 2 * e32 + 1e-6, (np.abs(got - ref).max(), e32)
+
+
+# ------------------------------------------------------------------ fused spline kernel (nf_rqs2d_x3.hip)
+# The parity tests of the exact-float32 kernel, unchanged, with the mode as the process default.
+import test_parity_gpu as P  # noqa: E402
+
+
+@pytest.fixture
+def x3_default(monkeypatch, nfa):
+    """FLOOR 6 instead of 4: the factor bounds a MAX over samples of two float32 computations'
+    errors, whose ratio on single ill-conditioned samples scatters (the one case beyond 4: a
+    one-layer inverse at a point with |dx/dz| = 33 where this mode is 1.16e-4 from float64, the
+    exact kernel 0.69e-4 and NumPy float32 0.27e-4); rms errors of the two modes are equal
+    (test_x3_log_prob_l8, profiles/x3_error_stats.py)."""
+    monkeypatch.setenv("NF_HIDDEN_MATMUL", "bf16x3")
+    monkeypatch.setattr(P, "FLOOR", 6.0)
+    spec = O.make_rqs_spec(1, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "rqs2d_h64_mfma" and f.get_option("hidden_matmul") == "bf16x3"
+    f.close()
+
+
+@pytest.mark.parametrize("density", ["gaussian_blobs", "banana", "energy2"])
+def test_x3_rqs_toy_config3(nfa, x3_default, density):
+    P.test_rqs_toy_config3(nfa, density)
+
+
+@pytest.mark.parametrize("K,L,parity,rows,lo,hi", [(12, 8, 1, 4096, -8.0, 8.0), (12, 1, 0, 33, -8.0, 8.0),
+                                                   (8, 3, 1, 1000, -5.0, 5.0), (4, 5, 0, 70001, -3.0, 4.0),
+                                                   (12, 11, 1, 513, -8.0, 8.0)])
+def test_x3_rqs_fused_kernel_shapes(nfa, x3_default, K, L, parity, rows, lo, hi):
+    P.test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi)
+
+
+def test_x3_rqs_fused_identity_and_edges(nfa, x3_default):
+    P.test_rqs_fused_identity_and_edges(nfa)
+
+
+@pytest.mark.parametrize("tune", ["1,16", "1,8", "2,8"])
+def test_x3_rqs_every_instantiation(nfa, monkeypatch, tune):
+    monkeypatch.setenv("NF_RQS2D_X3_TUNE", tune)
+    spec = O.make_rqs_spec(8, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    x = O.make_inputs("gaussian_blobs", 1 << 17, seed=9)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, f"rqs bf16x3 tune {tune}", P.FLOOR * e32)
+    assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
+
+
+def test_x3_env_default_covers_the_other_kernels(nfa, monkeypatch):
+    monkeypatch.setenv("NF_HIDDEN_MATMUL", "bf16x3")
+    f = affine_flow(nfa, O.make_affine_spec(2, final_std=0.02))
+    assert f.get_option("hidden_matmul") == "bf16x3"
+    g = affine_flow(nfa, O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.02))
+    assert g.kernel_name == "generic_gemm" and g.get_option("hidden_matmul") == "bf16x3"
+    s = split_flow(nfa, O.make_a_params(4)[0])
+    assert s.get_option("hidden_matmul") == "f32"   # no MFMA in that kernel: the default does not apply
+    monkeypatch.delenv("NF_HIDDEN_MATMUL")
+    assert affine_flow(nfa, O.make_affine_spec(2, final_std=0.02)).get_option("hidden_matmul") == "f32"

@@ -20,6 +20,12 @@ pytestmark = pytest.mark.gpu
 DENSITIES = ["banana", "energy1", "energy2", "energy3", "energy4", "gaussian_blobs"]
 
 
+# Spline-path intermediates: how many times the NumPy float32 restatement's own worst error on
+# the same batch a float32 kernel may be away from float64 (see assert_close).  4 is calibrated on
+# the exact-float32 kernels; tests/test_bf16x3_gpu.py re-runs these tests with its own value.
+FLOOR = 4.0
+
+
 def tol(ref):
     return 1e-5 * np.maximum(1.0, np.abs(ref))
 
@@ -365,17 +371,17 @@ def test_rqs_toy_config3(nfa, density):
     x = O.make_inputs(density, 4096)
     ref = O.log_prob(spec, x)
     lp32 = O.log_prob(spec, x, np.float32)
-    assert_close(f.log_prob(x), ref, f"rqs log_prob {density}", 4 * np.abs(lp32 - ref).max())
+    assert_close(f.log_prob(x), ref, f"rqs log_prob {density}", FLOOR * np.abs(lp32 - ref).max())
     z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
     zr, ldr = O.chain_forward(spec, x)
     z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "rqs z", 4 * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, "rqs logdet", 4 * np.abs(ld32 - ldr).max())
+    assert_close(z, zr, "rqs z", FLOOR * np.abs(z32 - zr).max())
+    assert_close(ld, ldr, "rqs logdet", FLOOR * np.abs(ld32 - ldr).max())
     xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
     xr, ldr2 = O.chain_inverse(spec, z)
     x32, ldi32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "rqs inverse", 4 * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr2, "rqs inverse logdet", 4 * np.abs(ldi32 - ldr2).max())
+    assert_close(xb, xr, "rqs inverse", FLOOR * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr2, "rqs inverse logdet", FLOOR * np.abs(ldi32 - ldr2).max())
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
 
 
@@ -492,17 +498,17 @@ def test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi):
     x = O.make_inputs("banana", rows, seed=K * 100 + L)   # banana leaves [-8, 8]: tails are exercised
     ref = O.log_prob(spec, x)
     e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, "fused rqs log_prob", 4 * e32)
+    assert_close(f.log_prob(x), ref, "fused rqs log_prob", FLOOR * e32)
     z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
     zr, ldr = O.chain_forward(spec, x)
     z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "fused rqs z", 4 * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, "fused rqs logdet", 4 * np.abs(ld32 - ldr).max())
+    assert_close(z, zr, "fused rqs z", FLOOR * np.abs(z32 - zr).max())
+    assert_close(ld, ldr, "fused rqs logdet", FLOOR * np.abs(ld32 - ldr).max())
     xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
     xr, ldr2 = O.chain_inverse(spec, z)
     x32, l32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "fused rqs inverse", 4 * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr2, "fused rqs inverse logdet", 4 * np.abs(l32 - ldr2).max())
+    assert_close(xb, xr, "fused rqs inverse", FLOOR * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr2, "fused rqs inverse logdet", FLOOR * np.abs(l32 - ldr2).max())
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
     for l in range(min(L, 3)):
         y, d = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, l, l + 1)
@@ -538,13 +544,13 @@ def test_rqs_general_path_register_kernel(nfa, monkeypatch, K, D, hidden, L, row
     x = (np.random.default_rng(K + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
     ref = O.log_prob(spec, x)
     e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, "general rqs log_prob", 4 * e32)
+    assert_close(f.log_prob(x), ref, "general rqs log_prob", FLOOR * e32)
     z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
     xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
     xr, ldr = O.chain_inverse(spec, z)
     x32, l32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "general rqs inverse", 4 * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr, "general rqs inverse logdet", 4 * np.abs(l32 - ldr).max())
+    assert_close(xb, xr, "general rqs inverse", FLOOR * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr, "general rqs inverse logdet", FLOOR * np.abs(l32 - ldr).max())
 
 
 # ------------------------------------------------------------------ backward pass / training step
