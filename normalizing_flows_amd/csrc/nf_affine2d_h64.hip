@@ -118,7 +118,7 @@ __device__ __forceinline__ float exp_f32(float x) {
 //   * the affine map uses the 6-instruction exp above, the direction is a template parameter,
 //   * four waves per SIMD (T = 2).
 template <int T, int WAVES, int INV>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) {
+__global__ __launch_bounds__(WAVES * 64, WAVES >= 4 ? WAVES / 4 : 1) void chain_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ChainIO& io = p.io;
   const int tid = threadIdx.x;
@@ -311,14 +311,22 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
   p.first_mask_parity = first_mask_parity;
   const size_t lds_bytes = (size_t)nlay * kLayerFloats * sizeof(float) + 128;
   const int cap = grid_cap > 0 && grid_cap < max_grid() ? grid_cap : max_grid();
-  const int waves = tune.waves == 8 ? 8 : 16;
+  int waves = tune.waves == 8 ? 8 : (tune.waves == 4 ? 4 : 16);
+  // small batches: waves of one workgroup share the CU's four MFMA pipes, so fewer waves per
+  // workgroup and more workgroups finish sooner (4096 rows: 35 us -> see profiles/bench_configs.py)
+  if (getenv("NF_AFFINE2D_TUNE") == nullptr) {
+    if (io.rows <= (long long)cap * 4 * 32) waves = 4;
+    else if (io.rows <= (long long)cap * 8 * 32) waves = 8;
+  }
   // tiles per wave: fewer for small batches so that they still spread over the chip
   int T = waves == 8 ? (tune.T == 4 ? 4 : 2) : (tune.T == 1 ? 1 : 2);
+  if (waves == 4) T = 1;
   while (T > 1 && io.rows < (long long)cap * waves * 32 * T) T >>= 1;
   const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
   long long want = (groups + waves - 1) / waves;
   int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
+  if (waves == 4) return launch_dir<1, 4>(p, grid, lds_bytes, stream);
   if (waves == 16)
     return T == 2 ? launch_dir<2, 16>(p, grid, lds_bytes, stream) : launch_dir<1, 16>(p, grid, lds_bytes, stream);
   if (T == 4) return launch_dir<4, 8>(p, grid, lds_bytes, stream);

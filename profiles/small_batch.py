@@ -1,0 +1,27 @@
+"""Latency of one log_prob call on device-resident rows for small batches (the reference trains and
+evaluates at batch 128), 8 layers, both hidden_matmul modes.   python profiles/small_batch.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import flows_np as O
+from normalizing_flows_amd import _lib, flow as nfa
+
+spec = O.make_affine_spec(8, final_std=0.02)
+cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), first_mask_parity=1)
+f = nfa.CouplingFlow(cfg, spec.layers)
+for rows in (128, 1024, 4096, 16384, 65536, 262144):
+    x = nfa.DeviceArray.from_numpy(O.make_inputs("banana", rows, seed=1))
+    out = nfa.DeviceArray((rows,))
+    line = f"rows {rows:7d}:"
+    for mode in ("f32", "bf16x3"):
+        f.set_option("hidden_matmul", mode)
+        for _ in range(20):
+            f.log_prob(x, out)
+        f.synchronize()
+        best = 1e9
+        for rep in range(5):
+            f.timer_start()
+            for _ in range(100):
+                f.log_prob(x, out)
+            best = min(best, f.timer_stop() / 100)
+        line += f"  {mode} {best * 1e3:7.1f} us/call ({rows / best / 1e3:8.1f} M evals/s)"
+    print(line, flush=True)
