@@ -127,6 +127,9 @@ struct nf_flow {
   // lazily from the canonical weights whenever they changed
   bool x3 = false, x3_stale = true;
   float* d_wimg_x3 = nullptr;
+  // PATH_RQS2D_H64 trains through the general plan (nf_generic_bwd.hip); the fused image is then
+  // rebuilt from the canonical weights the next time the fused kernel is asked for
+  bool wimg_stale = false;
   generic::Plan plan;       // PATH_GENERIC
   std::vector<float> h_weights;  // canonical weights as last set from the host
   // training state (PATH_AFFINE2D_H64; allocated on first use)
@@ -205,10 +208,14 @@ static int refresh_x3_image(nf_flow* f) {
   return NF_OK;
 }
 
+static int run_chain_plan(nf_flow* f, const ChainIO& io, int* out_grid);
+static int refresh_rqs_image(nf_flow* f);
+
 // Enqueue a chain walk on device pointers.  out_grid = number of block sums written.
 static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
   ChainIO io = io_in;
   io.base = f->desc.base;
+  if (f->path == PATH_RQS2D_H64 && f->wimg_stale) NF_TRY(refresh_rqs_image(f));
   if (f->x3 && (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64)) {
     if (f->x3_stale) NF_TRY(refresh_x3_image(f));
     if (f->path == PATH_RQS2D_H64) return rqs2d_x3::launch(f->d_wimg_x3, f->desc, io, f->stream, out_grid);
@@ -247,7 +254,11 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
     }
     return NF_OK;
   }
-  // general path: state lives in y / ld and is updated in place, layer by layer
+  return run_chain_plan(f, io, out_grid);
+}
+
+// general path: state lives in y / ld and is updated in place, layer by layer
+static int run_chain_plan(nf_flow* f, const ChainIO& io, int* out_grid) {
   const int D = f->desc.event_dim;
   if (!io.y || !io.logdet_out) NF_TRY(ensure_stage(f, io.rows));
   float* y = io.y ? io.y : f->d_y;
@@ -264,6 +275,31 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
   if (io.logprob_out || io.block_sums)
     NF_TRY(generic::launch_base_log_prob(y, ld, io.logprob_out, io.block_sums, io.rows, D, io.base,
                                          f->stream, out_grid));
+  return NF_OK;
+}
+
+// The fused spline kernel's weight image from canonical weights (host side).
+static void pack_rqs_images(const nf_flow_desc& d, const float* packed, size_t per_layer, std::vector<float>& img) {
+  const int P = 3 * d.rqs_bins + 1;
+  img.resize((size_t)d.num_layers * rqs2d::kLayerFloats);
+  for (int l = 0; l < d.num_layers; ++l) {
+    const float* W1 = packed + per_layer * l;
+    const float* b1 = W1 + 2 * 64;
+    const float* W2 = b1 + 64;
+    const float* b2 = W2 + 64 * 64;
+    const float* W3 = b2 + 64;
+    const float* b3 = W3 + 64 * 2 * P;
+    rqs2d::pack_layer(W1, b1, W2, b2, W3, b3, (d.first_mask_parity + l) & 1, d.rqs_bins,
+                      img.data() + (size_t)l * rqs2d::kLayerFloats);
+  }
+}
+
+static int refresh_rqs_image(nf_flow* f) {
+  std::vector<float> w(f->weight_count), img;
+  NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));  // synchronises, downloads the trained weights
+  pack_rqs_images(f->desc, w.data(), f->weight_count / f->desc.num_layers, img);
+  NF_HIP(hipMemcpy(f->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  f->wimg_stale = false;
   return NF_OK;
 }
 
@@ -452,18 +488,8 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
       affine2d::pack_layer(W1, b1, W2, b2, W3, b3, cond_dim, img.data() + (size_t)l * affine2d::kLayerFloats);
     }
   } else if (f->path == PATH_RQS2D_H64) {
-    const int P = 3 * d.rqs_bins + 1;
-    img.resize((size_t)d.num_layers * rqs2d::kLayerFloats);
-    for (int l = 0; l < d.num_layers; ++l) {
-      const float* W1 = packed + per_layer * l;
-      const float* b1 = W1 + 2 * 64;
-      const float* W2 = b1 + 64;
-      const float* b2 = W2 + 64 * 64;
-      const float* W3 = b2 + 64;
-      const float* b3 = W3 + 64 * 2 * P;
-      rqs2d::pack_layer(W1, b1, W2, b2, W3, b3, (d.first_mask_parity + l) & 1, d.rqs_bins,
-                        img.data() + (size_t)l * rqs2d::kLayerFloats);
-    }
+    pack_rqs_images(d, packed, per_layer, img);
+    f->wimg_stale = false;
   } else if (f->path == PATH_SPLIT2D_SMALL) {
     // W0[1][H], b0[H], W1[H][2], b1[2] is already the kernel's order
     img.assign(packed, packed + count);
@@ -471,6 +497,13 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
     NF_HIP(hipStreamSynchronize(f->stream));
     NF_TRY(f->plan.build(d, packed));
     f->have_weights = true;
+    if (f->train.ready) {  // a training state exists: restart it from the new weights
+      NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
+      NF_HIP(hipMemset(f->train.d_m, 0, count * sizeof(float)));
+      NF_HIP(hipMemset(f->train.d_v, 0, count * sizeof(float)));
+      f->train.step = 0;
+      NF_TRY(f->plan.prepare_backward());
+    }
     return NF_OK;
   }
   NF_HIP(hipStreamSynchronize(f->stream));
@@ -482,6 +515,11 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
     NF_HIP(hipMemset(f->train.d_m, 0, count * sizeof(float)));
     NF_HIP(hipMemset(f->train.d_v, 0, count * sizeof(float)));
     f->train.step = 0;
+  }
+  if (f->train.ready && f->path == PATH_RQS2D_H64) {
+    NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
+    NF_TRY(f->plan.build(d, packed));
+    NF_TRY(f->plan.prepare_backward());
   }
   if (f->train.ready && f->path == PATH_AFFINE2D_H64) {
     NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
@@ -812,16 +850,39 @@ static int upload(T** dst, const std::vector<T>& host) {
   return NF_OK;
 }
 
+// flows whose gradient comes from the general plan: every masked kind without a fused backward
+static const nf_flow_desc& d_of(const nf_flow* f) { return f->desc; }
+static bool trains_through_plan(const nf_flow* f) {
+  const int k = f->desc.kind;
+  return (f->path == PATH_GENERIC || f->path == PATH_RQS2D_H64) &&
+         (k == NF_KIND_AFFINE_MASKED || k == NF_KIND_RQS_MASKED);
+}
+
 static int ensure_train(nf_flow* f, long long rows) {
   const bool split = f->path == PATH_SPLIT2D_SMALL && split2d::bwd_supported(f->desc.hidden[0]);
-  if (f->path != PATH_AFFINE2D_H64 && !split) {
-    set_error("the backward pass is built for the fused masked-affine flow (D = 2, conditioner 2-64-64-2) and the "
-              "split flow of src/real_nvp.py (D = 2, MLP 1-H-2, H = 4, 8, 16)");
+  const bool planned = trains_through_plan(f);
+  if (f->path != PATH_AFFINE2D_H64 && !split && !planned) {
+    set_error("the backward pass is built for the masked coupling kinds (affine and spline, any event size) and "
+              "the split flow of src/real_nvp.py (D = 2, MLP 1-H-2, H = 4, 8, 16)");
     return NF_ERR_UNSUPPORTED;
   }
   nf_flow::Train& t = f->train;
   const nf_flow_desc& d = f->desc;
   const size_t n = f->weight_count;
+  if (!t.ready && planned) {
+    // canonical weights + Adam state on the device; gradients come from generic::Plan::backward
+    NF_HIP(hipMalloc(&t.d_canon, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_m, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_v, n * sizeof(float)));
+    NF_HIP(hipMemcpy(t.d_canon, f->h_weights.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
+    NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
+    if (f->path == PATH_RQS2D_H64) NF_TRY(f->plan.build(d, f->h_weights.data()));
+    NF_TRY(f->plan.prepare_backward());
+    t.step = 0;
+    t.ready = true;
+  }
   if (!t.ready && split) {
     // the split kernels read the canonical layout directly: d_wimg IS the weight vector
     NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
@@ -870,8 +931,8 @@ static int ensure_train(nf_flow* f, long long rows) {
     hipFree(t.d_state_v); hipFree(t.d_state_g);
     t.d_state_v = t.d_state_g = nullptr;
     t.state_rows = 0;
-    NF_HIP(hipMalloc(&t.d_state_v, sizeof(float) * 2 * rows));
-    NF_HIP(hipMalloc(&t.d_state_g, sizeof(float) * 2 * rows));
+    NF_HIP(hipMalloc(&t.d_state_v, sizeof(float) * d.event_dim * rows));
+    NF_HIP(hipMalloc(&t.d_state_g, sizeof(float) * d.event_dim * rows));
     t.state_rows = rows;
   }
   return NF_OK;
@@ -897,7 +958,18 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
     io.y = t.d_state_v;
     io.block_sums = sums;
     io.add_base = 1;
-    NF_TRY(run_chain_device(f, io, &grid));
+    io.base = d.base;
+    // spline flows on the fused kernel train through the plan as well: its weights follow every
+    // optimiser step on the device, the fused image is rebuilt on the host only when next needed
+    if (trains_through_plan(f)) {
+      NF_TRY(f->plan.ensure_tape(rows_local));
+      f->plan.record_tape = true;
+      const int s = run_chain_plan(f, io, &grid);
+      f->plan.record_tape = false;
+      NF_TRY(s);
+    } else {
+      NF_TRY(run_chain_device(f, io, &grid));
+    }
   }
   NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));
   NF_HIP(hipStreamWaitEvent(f->side, f->ev_kernel[slot], 0));
@@ -908,6 +980,11 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   f->tail_pending[slot] = true;
   f->ring_rows[slot] = rows_global;
   // backward: the layer log_prob applied last (layer 0) first
+  if (trains_through_plan(f)) {
+    NF_TRY(f->plan.backward(t.d_state_v, t.d_state_g, rows_local, rows_global, t.d_grad, f->weight_count, f->stream));
+    if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+    return NF_OK;
+  }
   if (f->path == PATH_SPLIT2D_SMALL) {
     const int H = d.hidden[0], per = split2d::layer_floats(H);
     for (int l = 0; l < d.num_layers; ++l)
@@ -984,6 +1061,17 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
                          (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
     NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
                          (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+  }
+  if (trains_through_plan(f)) {
+    NF_TRY(f->plan.refresh_from_canonical(t.d_canon, f->stream));
+    if (f->path == PATH_RQS2D_H64) f->wimg_stale = true;
+    if (f->plan.x3) {  // the split-bf16 weight images are built on the host
+      std::vector<float> w(f->weight_count);
+      t.dirty = true;
+      NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));
+      NF_TRY(f->plan.build(d_of(f), w.data()));
+      NF_TRY(f->plan.prepare_backward());
+    }
   }
   t.dirty = true;
   f->x3_stale = true;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
     }
 }
 
-static int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
+int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
                        int M, int N, int K, int act, hipStream_t stream) {
   const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
@@ -296,10 +296,6 @@ __global__ __launch_bounds__(256) void affine_split_kernel(float* __restrict__ y
   }
 }
 
-struct RqsConst {
-  int K;
-  float range_min, range_max, min_bin, min_slope, slope_offset;
-};
 
 __device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
 
@@ -746,6 +742,7 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   max_width = 0;
   act_width = 0;
   std::vector<float> host;
+  canon_index.clear();
   linears.assign((size_t)d.num_layers * nlin, Linear());
   for (int l = 0; l < d.num_layers; ++l) {
     const float* src = packed + per_layer * l;
@@ -759,11 +756,15 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
       L.N = out[j];
       std::vector<float> w(W, W + (size_t)in[j] * out[j]);
       std::vector<float> bb(b, b + out[j]);
+      // where each kept value sits in `packed` (-1: a structural zero): weights, then biases
+      std::vector<int> wi(w.size()), bi(bb.size());
+      for (size_t q = 0; q < w.size(); ++q) wi[q] = (int)(W - packed + q);
+      for (size_t q = 0; q < bb.size(); ++q) bi[q] = (int)(b - packed + q);
       if (d.kind != NF_KIND_AFFINE_SPLIT && j == 0) {
         // where(mask, x, 0) @ W  ==  x @ W with the transformed dims' rows zeroed
         for (int r = 0; r < in[j]; ++r)
           if ((r & 1) != pass_parity)
-            for (int c = 0; c < out[j]; ++c) w[(size_t)r * out[j] + c] = 0.f;
+            for (int c = 0; c < out[j]; ++c) { w[(size_t)r * out[j] + c] = 0.f; wi[(size_t)r * out[j] + c] = -1; }
       }
       if (d.kind == NF_KIND_RQS_MASKED && j == nlin - 1) {
         // keep the parameter columns of the transformed dims only
@@ -772,14 +773,21 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
         for (int e = 0; e < D; ++e) if ((e & 1) != pass_parity) tdims.push_back(e);
         const int Nn = (int)tdims.size() * P;
         std::vector<float> w2((size_t)in[j] * Nn), b2(Nn);
+        std::vector<int> wi2(w2.size()), bi2(Nn);
         for (size_t t = 0; t < tdims.size(); ++t)
           for (int q = 0; q < P; ++q) {
             const int cs = tdims[t] * P + q, cd = (int)t * P + q;
             b2[cd] = bb[cs];
-            for (int r = 0; r < in[j]; ++r) w2[(size_t)r * Nn + cd] = w[(size_t)r * out[j] + cs];
+            bi2[cd] = bi[cs];
+            for (int r = 0; r < in[j]; ++r) {
+              w2[(size_t)r * Nn + cd] = w[(size_t)r * out[j] + cs];
+              wi2[(size_t)r * Nn + cd] = wi[(size_t)r * out[j] + cs];
+            }
           }
         w.swap(w2);
         bb.swap(b2);
+        wi.swap(wi2);
+        bi.swap(bi2);
         L.N = Nn;
       }
       max_width = std::max(max_width, L.N);
@@ -787,10 +795,12 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
       else param_width = std::max(param_width, L.N);
       L.w_off = host.size();
       host.insert(host.end(), w.begin(), w.end());
-      while (host.size() % 4) host.push_back(0.f);
+      canon_index.insert(canon_index.end(), wi.begin(), wi.end());
+      while (host.size() % 4) { host.push_back(0.f); canon_index.push_back(-1); }
       L.b_off = host.size();
       host.insert(host.end(), bb.begin(), bb.end());
-      while (host.size() % 4) host.push_back(0.f);
+      canon_index.insert(canon_index.end(), bi.begin(), bi.end());
+      while (host.size() % 4) { host.push_back(0.f); canon_index.push_back(-1); }
     }
   }
   NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
@@ -821,6 +831,9 @@ int Plan::set_x3(bool on) {
 
 void Plan::release() {
   if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
+  hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
+  hipFree(bwd.d_scratch); hipFree(bwd.d_tape);
+  bwd = Backward();
   if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }
   host_weights.clear();
   if (d_scratch) { hipFree(d_scratch); d_scratch = nullptr; }
@@ -843,6 +856,48 @@ int Plan::ensure_scratch(long long rows) {
   return NF_OK;
 }
 
+RqsConst make_rqs_const(const nf_flow_desc& d) {
+  RqsConst rc;
+  rc.K = d.rqs_bins;
+  rc.range_min = d.rqs_range_min;
+  rc.range_max = d.rqs_range_max;
+  rc.min_bin = d.rqs_min_bin_size;
+  rc.min_slope = d.rqs_min_knot_slope;
+  rc.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
+  return rc;
+}
+
+// One coupling transform on rows [0, n): y and ld updated in place from the conditioner output.
+int launch_transform(const nf_flow_desc& d, float* yc, float* ldc, const float* params, long long n, int par,
+                     int inverse_op, const RqsConst& rc, hipStream_t stream) {
+  const int D = d.event_dim;
+  if (d.kind == NF_KIND_AFFINE_MASKED) {
+    const long long total = n * D;
+    const int grid = (int)std::min<long long>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(affine_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par, inverse_op);
+  } else if (d.kind == NF_KIND_AFFINE_SPLIT) {
+    const int grid = (int)std::min<long long>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(affine_split_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par, inverse_op);
+  } else {
+    bool done = false;
+    if (getenv("NF_RQS_SIMPLE") == nullptr) {
+      if (rc.K == 8) done = launch_rqs_rows<8>(yc, ldc, params, n, D, par, inverse_op, rc, stream);
+      else if (rc.K == 12) done = launch_rqs_rows<12>(yc, ldc, params, n, D, par, inverse_op, rc, stream);
+    }
+    if (!done) {
+      const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+      int G = 1;
+      while (G < 64 && G < Dt) G <<= 1;
+      const long long lanes = n * G;
+      const int grid = (int)std::min<long long>(8192, (lanes + 255) / 256);
+      hipLaunchKernelGGL(rqs_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par, inverse_op,
+                         G, rc);
+    }
+  }
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // y (in place) and ld (in place) already hold the chain's input state.
 int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
   const nf_flow_desc& d = desc;
@@ -851,13 +906,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
   const int nlay = io.layer_end - io.layer_begin;
   NF_TRY(ensure_scratch(io.rows));
   const int act = d.activation == NF_ACT_RELU ? 1 : 2;
-  RqsConst rc;
-  rc.K = d.rqs_bins;
-  rc.range_min = d.rqs_range_min;
-  rc.range_max = d.rqs_range_max;
-  rc.min_bin = d.rqs_min_bin_size;
-  rc.min_slope = d.rqs_min_knot_slope;
-  rc.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
+  const RqsConst rc = make_rqs_const(d);
   for (long long r0 = 0; r0 < io.rows; r0 += scratch_rows) {
     const long long n = std::min(scratch_rows, io.rows - r0);
     float* yc = y + r0 * D;
@@ -867,6 +916,9 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
     for (int li = 0; li < nlay; ++li) {
       const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
       const int par = (d.first_mask_parity + l) & 1;  // masked: pass-through parity; split: flip
+      if (record_tape)  // training: keep every layer's input (indexed by LAYER, not by position)
+        NF_HIP(hipMemcpyAsync(bwd.d_tape + ((size_t)l * bwd.tape_rows + r0) * D, yc, sizeof(float) * n * D,
+                              hipMemcpyDeviceToDevice, stream));
       const float* a = yc;
       int lda = D;
       if (d.kind == NF_KIND_AFFINE_SPLIT && par) a = yc + D / 2;  // flipped: second half conditions
@@ -882,31 +934,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         a = dst;
         lda = L.N;
       }
-      const float* params = buf[2];
-      if (d.kind == NF_KIND_AFFINE_MASKED) {
-        const long long total = n * D;
-        const int grid = (int)std::min<long long>(4096, (total + 255) / 256);
-        hipLaunchKernelGGL(affine_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
-                           io.inverse_op);
-      } else if (d.kind == NF_KIND_AFFINE_SPLIT) {
-        const int grid = (int)std::min<long long>(4096, (n + 255) / 256);
-        hipLaunchKernelGGL(affine_split_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
-                           io.inverse_op);
-      } else {
-        bool done = false;
-        if (getenv("NF_RQS_SIMPLE") == nullptr) {
-          if (rc.K == 8) done = launch_rqs_rows<8>(yc, ldc, params, n, D, par, io.inverse_op, rc, stream);
-          else if (rc.K == 12) done = launch_rqs_rows<12>(yc, ldc, params, n, D, par, io.inverse_op, rc, stream);
-        }
-        if (done) { NF_HIP(hipGetLastError()); continue; }
-        const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
-        int G = 1;
-        while (G < 64 && G < Dt) G <<= 1;
-        const long long lanes = n * G;
-        const int grid = (int)std::min<long long>(8192, (lanes + 255) / 256);
-        hipLaunchKernelGGL(rqs_masked_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par,
-                           io.inverse_op, G, rc);
-      }
+      NF_TRY(launch_transform(d, yc, ldc, buf[2], n, par, io.inverse_op, rc, stream));
       NF_HIP(hipGetLastError());
     }
   }

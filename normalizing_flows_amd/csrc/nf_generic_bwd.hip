@@ -1,0 +1,531 @@
+// General path, training: d(NLL)/d(weights) for the masked coupling kinds (affine and
+// rational-quadratic spline) of any event size and conditioner widths -- what jax.grad(loss_fn)
+// computes in src/real_nvp_toy_densities.py:164-173, src/maf_toy_densities.py:167-176 and
+// src/maf_mnist.py:159-168.  SURVEY.md 8f rank 2 ("backward of K1 / K4").
+//
+// The forward walk keeps every layer's INPUT (rows x D floats per layer: 64 MB for the 2-D flows at
+// batch 2^20, 1.2 GB for the MNIST shape at 2^16 -- small change against 288 GB of HBM); hidden
+// activations and conditioner outputs are NOT kept.  Going back through the chain, every layer
+//   1. re-runs the conditioner on its recorded input                       -> a_1 .. a_n, theta
+//   2. (nothing to invert: unlike the affine map, a spline's float32 inverse can be off by
+//      1e-4 where |dx/dy| is large, and the parameter gradients inherit that error -- measured)
+//   3. transform backward: d theta and dL/dx of the transformed dims from dL/dy and dL/d(logdet)
+//   4. MLP backward: dW_j += a_{j-1}^T g (rows on the MFMA k dimension, fixed-order partial sums),
+//      db_j += column sums, g <- (g W_j^T) * act'(a_{j-1}) (the forward GEMM kernels on a
+//      transposed copy of W_j), and finally dL/dx of the pass-through dims += g W_1^T.
+// Gradients are accumulated in the plan's own weight layout (masked rows / pruned columns are
+// structural zeros there) and scattered to the canonical layout at the end.
+//
+// The spline's partial derivatives are not hand-derived: the rational-quadratic formula is
+// evaluated on dual numbers carrying the seven partials (x, the bin's two knots on each axis, its
+// two slopes), forward mode; softmax / cumulative-sum / softplus are reversed by hand.
+#include "nf_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+namespace nf {
+namespace generic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- small kernels ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict__ z, float* __restrict__ g,
+                                                        long long total, int base, float inv_n) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
+    g[q] = base == NF_BASE_STD_NORMAL ? z[q] * inv_n : 0.f;  // -d/dz log N(z; 0, 1) = z
+}
+
+__global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ g, const float* __restrict__ a,
+                                                       long long total, int act) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const float v = a[q];  // post-activation value: its sign is the pre-activation's
+    g[q] = v > 0.f ? g[q] : (act == 2 ? 0.01f * g[q] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                  long long total) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
+    dst[q] += src[q];
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int K,
+                                                        int N) {
+  const long long total = (long long)K * N;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int n = (int)(q / K), k = (int)(q % K);
+    WT[q] = W[(size_t)k * N + n];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_weights_kernel(const float* __restrict__ canon,
+                                                             const int* __restrict__ index, float* __restrict__ w,
+                                                             long long total) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
+    w[q] = index[q] >= 0 ? canon[index[q]] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void scatter_grad_kernel(const float* __restrict__ g, const int* __restrict__ index,
+                                                           float* __restrict__ canon_grad, long long total) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
+    if (index[q] >= 0) canon_grad[index[q]] = g[q];
+}
+
+// ---- masked affine: y_t = x_t exp(ls) + shift on the transformed dims, logdet = n_t ls -----------
+// v holds the layer's INPUT.  th[row] = (shift, ls).  G: dL/dy in, dL/dx (transformed dims) out.
+__global__ __launch_bounds__(256) void affine_masked_bwd_kernel(const float* __restrict__ v, float* __restrict__ G,
+                                                                const float* __restrict__ th,
+                                                                float* __restrict__ dth, long long rows, int D,
+                                                                int pass_parity, float gld) {
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    const float e = __expf(th[2 * r + 1]);
+    float gs = 0.f, gl = 0.f;
+    int nt = 0;
+    for (int d = 0; d < D; ++d)
+      if ((d & 1) != pass_parity) {
+        const float gy = G[r * D + d];
+        gs += gy;
+        gl += gy * v[r * D + d] * e;
+        G[r * D + d] = gy * e;
+        ++nt;
+      }
+    dth[2 * r + 0] = gs;
+    dth[2 * r + 1] = gl + gld * nt;
+  }
+}
+
+// ---- spline ------------------------------------------------------------------------------------
+struct D7 {
+  float v, d[7];
+};
+__device__ __forceinline__ D7 d7_var(float v, int which) {
+  D7 r;
+  r.v = v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = j == which ? 1.f : 0.f;
+  return r;
+}
+__device__ __forceinline__ D7 operator+(const D7& a, const D7& b) {
+  D7 r;
+  r.v = a.v + b.v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = a.d[j] + b.d[j];
+  return r;
+}
+__device__ __forceinline__ D7 operator-(const D7& a, const D7& b) {
+  D7 r;
+  r.v = a.v - b.v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = a.d[j] - b.d[j];
+  return r;
+}
+__device__ __forceinline__ D7 operator*(const D7& a, const D7& b) {
+  D7 r;
+  r.v = a.v * b.v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = a.d[j] * b.v + a.v * b.d[j];
+  return r;
+}
+__device__ __forceinline__ D7 operator/(const D7& a, const D7& b) {
+  D7 r;
+  const float inv = 1.f / b.v;
+  r.v = a.v * inv;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * inv;
+  return r;
+}
+__device__ __forceinline__ D7 d7_scale(const D7& a, float c) {
+  D7 r;
+  r.v = a.v * c;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = a.d[j] * c;
+  return r;
+}
+__device__ __forceinline__ D7 d7_log(const D7& a) {
+  D7 r;
+  const float inv = 1.f / a.v;
+  r.v = logf(a.v);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = a.d[j] * inv;
+  return r;
+}
+__device__ __forceinline__ D7 d7_one_minus(const D7& a) {
+  D7 r;
+  r.v = 1.f - a.v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r.d[j] = -a.d[j];
+  return r;
+}
+
+__device__ __forceinline__ float softplus_bwd(float v) { return fmaxf(v, 0.f) + log1pf(__expf(-fabsf(v))); }
+__device__ __forceinline__ float sigmoid_bwd(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// One (row, transformed dim).  p: the 3K+1 raw parameters, gp: their gradient (written, all of it).
+// x: the layer's input value; gy = dL/dy; gld = dL/d(logdet).  Returns dL/dx.
+template <int KMAX>
+__device__ float rqs_bwd_one(const float* __restrict__ p, float* __restrict__ gp, const RqsConst& c, float x,
+                             float gy, float gld) {
+  const int K = c.K;
+  const float total = c.range_max - c.range_min;
+  const float cs = total - (float)K * c.min_bin;
+  // softmax of the width / height logits
+  float sw[KMAX], sh[KMAX];
+  float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
+  float sumw = 0.f, sumh = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      sw[k] = __expf(p[k] - mw);
+      sh[k] = __expf(p[K + k] - mh);
+      sumw += sw[k];
+      sumh += sh[k];
+    }
+  const float iw = 1.f / sumw, ih = 1.f / sumh;
+  // find the bin on the x axis while accumulating both axes' knots
+  int kb = 0;
+  float xl = c.range_min, yl = c.range_min, xr = c.range_max, yr = c.range_max;
+  {
+    float kx = c.range_min, ky = c.range_min;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        sw[k] *= iw;
+        sh[k] *= ih;
+        const float nx = k == K - 1 ? c.range_max : kx + fmaf(sw[k], cs, c.min_bin);
+        const float ny = k == K - 1 ? c.range_max : ky + fmaf(sh[k], cs, c.min_bin);
+        if (!found && (x < nx || k == K - 1)) {
+          found = true;
+          kb = k;
+          xl = kx; xr = nx; yl = ky; yr = ny;
+        }
+        kx = nx;
+        ky = ny;
+      }
+  }
+  const bool below = x <= c.range_min, above = x >= c.range_max;
+  float g_xl = 0.f, g_xr = 0.f, g_yl = 0.f, g_yr = 0.f, g_sl = 0.f, g_sr = 0.f, gx;
+  int ksl = kb, ksr = kb + 1;
+  if (below || above) {
+    const int ks = below ? 0 : K;
+    const float raw = p[2 * K + ks] + c.slope_offset;
+    const float s = softplus_bwd(raw) + c.min_slope;
+    gx = gy * s;
+    g_sl = gy * (x - (below ? c.range_min : c.range_max)) + gld / s;
+    ksl = ks;
+    ksr = -1;
+  } else {
+    const float rl = p[2 * K + kb] + c.slope_offset, rr = p[2 * K + kb + 1] + c.slope_offset;
+    const D7 X = d7_var(x, 0), XL = d7_var(xl, 1), XR = d7_var(xr, 2), YL = d7_var(yl, 3), YR = d7_var(yr, 4);
+    const D7 SL = d7_var(softplus_bwd(rl) + c.min_slope, 5), SR = d7_var(softplus_bwd(rr) + c.min_slope, 6);
+    const D7 w = XR - XL, hgt = YR - YL;
+    const D7 delta = hgt / w;
+    const D7 z = (X - XL) / w;
+    const D7 zz = z * z;
+    const D7 z1mz = z - zz;
+    const D7 omz = d7_one_minus(z);
+    const D7 st = SR + SL - d7_scale(delta, 2.f);
+    const D7 den = delta + st * z1mz;
+    const D7 y = YL + hgt * (delta * zz + SL * z1mz) / den;
+    const D7 ld = d7_scale(d7_log(delta), 2.f) + d7_log(SR * zz + d7_scale(delta * z1mz, 2.f) + SL * omz * omz) -
+                  d7_scale(d7_log(den), 2.f);
+    float g7[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) g7[j] = gy * y.d[j] + gld * ld.d[j];
+    gx = g7[0];
+    g_xl = g7[1]; g_xr = g7[2]; g_yl = g7[3]; g_yr = g7[4];
+    g_sl = g7[5]; g_sr = g7[6];
+  }
+  // slopes: s = softplus(raw + offset) + min_slope
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k)
+    if (k <= K) {
+      float g = 0.f;
+      if (k == ksl) g = g_sl;
+      else if (k == ksr) g = g_sr;
+      gp[2 * K + k] = g != 0.f ? g * sigmoid_bwd(p[2 * K + k] + c.slope_offset) : 0.f;
+    }
+  // knots -> bin sizes: knot[k] = min + sum_{j<k} size_j for 1 <= k <= K-1 (knot 0 and K are constants),
+  // so d/d size_j = sum of the knot gradients with index > j: only knots kb and kb+1 carry any
+  const float gxl = kb >= 1 ? g_xl : 0.f, gxr = kb + 1 <= K - 1 ? g_xr : 0.f;
+  const float gyl = kb >= 1 ? g_yl : 0.f, gyr = kb + 1 <= K - 1 ? g_yr : 0.f;
+  float dotw = 0.f, doth = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      const float gw = (k < kb ? gxl : 0.f) + (k <= kb ? gxr : 0.f);
+      const float gh = (k < kb ? gyl : 0.f) + (k <= kb ? gyr : 0.f);
+      dotw += gw * sw[k];
+      doth += gh * sh[k];
+    }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      const float gw = (k < kb ? gxl : 0.f) + (k <= kb ? gxr : 0.f);
+      const float gh = (k < kb ? gyl : 0.f) + (k <= kb ? gyr : 0.f);
+      gp[k] = cs * sw[k] * (gw - dotw);
+      gp[K + k] = cs * sh[k] * (gh - doth);
+    }
+  return gx;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void rqs_masked_bwd_kernel(const float* __restrict__ v, float* __restrict__ G,
+                                                             const float* __restrict__ th, float* __restrict__ dth,
+                                                             long long rows, int D, int pass_parity, float gld,
+                                                             RqsConst c) {
+  const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
+  const int P = 3 * c.K + 1;
+  const long long total = rows * Dt;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const long long r = q / Dt;
+    const int t = (int)(q % Dt);
+    const int d = 2 * t + (pass_parity == 0 ? 1 : 0);
+    const size_t po = (size_t)r * Dt * P + (size_t)t * P;
+    G[r * D + d] = rqs_bwd_one<KMAX>(th + po, dth + po, c, v[r * D + d], G[r * D + d], gld);
+  }
+}
+
+// ---- weight gradient: C[K, N] (+)= A[rows, K]^T B[rows, N], rows on the MFMA k dimension --------
+// One workgroup: a 32 x 32 tile of C over one chunk of rows, split between its 4 waves and added
+// through LDS in a fixed order.  A == nullptr: a column of ones (K = 1): column sums, for the biases.
+__global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ B, int ldb,
+                                                         float* __restrict__ partial, long long rows,
+                                                         long long chunk_rows, int K, int N, int tiles_n) {
+  __shared__ float red[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int k0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const long long c0 = (long long)blockIdx.y * chunk_rows;
+  const long long c1 = std::min(rows, c0 + chunk_rows);
+  long long per = ((c1 - c0 + 3) / 4 + 1) & ~1LL;  // even, so that a wave's 2-row steps stay aligned
+  const long long m0 = c0 + wave * per, m1 = std::min(c1, m0 + per);
+  const bool kin = k0 + i < K, nin = n0 + i < N;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (long long m = m0; m < m1; m += 2) {
+    const long long row = m + h;
+    const bool ok = row < m1;
+    const float a = (ok && kin) ? (A ? A[row * lda + k0 + i] : 1.f) : 0.f;
+    const float b = (ok && nin) ? B[row * ldb + n0 + i] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.y * K * N;
+  for (int q = threadIdx.x; q < 1024; q += 256) {
+    const int r = q >> 6, l = q & 63;
+    const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), nn = n0 + (l & 31);
+    if (kk < K && nn < N) out[(size_t)kk * N + nn] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+  }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int nchunks, size_t count,
+                                                        float* __restrict__ grad) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * count + q];
+    grad[q] += s;
+  }
+}
+
+static int grid_for(long long total, int cap = 8192) {
+  return (int)std::max<long long>(1, std::min<long long>(cap, (total + 255) / 256));
+}
+
+// grad[K*N] += A^T B
+static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long long rows, int K, int N, float* grad,
+                         float* partials, size_t partial_floats, hipStream_t stream) {
+  const size_t count = (size_t)K * N;
+  int nchunks = (int)std::min<long long>(64, std::max<long long>(1, (rows + 2047) / 2048));
+  nchunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)nchunks, partial_floats / count));
+  long long chunk_rows = (rows + nchunks - 1) / nchunks;
+  chunk_rows = (chunk_rows + 1) & ~1LL;
+  nchunks = (int)((rows + chunk_rows - 1) / chunk_rows);
+  const int tiles_k = (K + 31) / 32, tiles_n = (N + 31) / 32;
+  hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, nchunks), dim3(256), 0, stream, A, lda, B, ldb,
+                     partials, rows, chunk_rows, K, N, tiles_n);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid_for((long long)count, 2048)), dim3(256), 0, stream, partials, nchunks,
+                     count, grad);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+// ---- host ----------------------------------------------------------------------------------
+int Plan::prepare_backward() {
+  Backward& b = bwd;
+  if (desc.kind != NF_KIND_AFFINE_MASKED && desc.kind != NF_KIND_RQS_MASKED) {
+    set_error("the general backward pass covers the masked coupling kinds");
+    return NF_ERR_UNSUPPORTED;
+  }
+  if (desc.kind == NF_KIND_RQS_MASKED && desc.rqs_bins > 32) {
+    set_error("the spline backward kernel is built for up to 32 bins");
+    return NF_ERR_UNSUPPORTED;
+  }
+  hipFree(b.d_grad); hipFree(b.d_wT); hipFree(b.d_canon_index); hipFree(b.d_zero); hipFree(b.d_partials);
+  b.d_grad = b.d_wT = b.d_zero = b.d_partials = nullptr;
+  b.d_canon_index = nullptr;
+  b.ready = false;
+  b.n_weights = host_weights.size();
+  NF_HIP(hipMalloc(&b.d_grad, b.n_weights * sizeof(float)));
+  NF_HIP(hipMalloc(&b.d_canon_index, b.n_weights * sizeof(int)));
+  NF_HIP(hipMemcpy(b.d_canon_index, canon_index.data(), b.n_weights * sizeof(int), hipMemcpyHostToDevice));
+  size_t wt = 0, biggest = 0;
+  int widest = desc.event_dim;
+  b.wT_off.clear();
+  for (const Linear& L : linears) {
+    b.wT_off.push_back(wt);
+    wt += ((size_t)L.K * L.N + 3) / 4 * 4;
+    biggest = std::max(biggest, (size_t)L.K * L.N);
+    widest = std::max(widest, std::max(L.K, L.N));
+  }
+  NF_HIP(hipMalloc(&b.d_wT, wt * sizeof(float)));
+  NF_HIP(hipMalloc(&b.d_zero, (size_t)widest * sizeof(float)));
+  NF_HIP(hipMemset(b.d_zero, 0, (size_t)widest * sizeof(float)));
+  // up to 16 row-chunk slabs of the largest Linear, at most 512 MiB
+  b.partial_floats = std::max(biggest, std::min<size_t>(biggest * 16, ((size_t)512 << 20) / sizeof(float)));
+  NF_HIP(hipMalloc(&b.d_partials, b.partial_floats * sizeof(float)));
+  for (size_t q = 0; q < linears.size(); ++q) {
+    const Linear& L = linears[q];
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)L.K * L.N, 2048)), dim3(256), 0, 0,
+                       d_weights + L.w_off, b.d_wT + b.wT_off[q], L.K, L.N);
+  }
+  NF_HIP(hipGetLastError());
+  NF_HIP(hipDeviceSynchronize());
+  b.ready = true;
+  return NF_OK;
+}
+
+int Plan::refresh_from_canonical(const float* d_canon, hipStream_t stream) {
+  Backward& b = bwd;
+  hipLaunchKernelGGL(gather_weights_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream,
+                     d_canon, b.d_canon_index, d_weights, (long long)b.n_weights);
+  for (size_t q = 0; q < linears.size(); ++q) {
+    const Linear& L = linears[q];
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)L.K * L.N, 2048)), dim3(256), 0, stream,
+                       d_weights + L.w_off, b.d_wT + b.wT_off[q], L.K, L.N);
+  }
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+int Plan::ensure_tape(long long rows) {
+  Backward& b = bwd;
+  if (rows <= b.tape_rows) return NF_OK;
+  const size_t bytes = sizeof(float) * (size_t)desc.num_layers * rows * desc.event_dim;
+  if (bytes > ((size_t)64 << 30)) {
+    set_error("training batch needs %zu bytes of layer inputs, more than the 64 GiB this build allows", bytes);
+    return NF_ERR_UNSUPPORTED;
+  }
+  hipFree(b.d_tape);
+  b.d_tape = nullptr;
+  b.tape_rows = 0;
+  NF_HIP(hipMalloc(&b.d_tape, bytes));
+  b.tape_rows = rows;
+  return NF_OK;
+}
+
+int Plan::backward(const float* v, float* g, long long rows, long long rows_global, float* grad_canon,
+                   size_t weight_count, hipStream_t stream) {
+  Backward& b = bwd;
+  if (!b.ready) { set_error("Plan::prepare_backward has not run"); return NF_ERR_STATE; }
+  if (rows > b.tape_rows) { set_error("Plan::backward without a recorded forward walk"); return NF_ERR_STATE; }
+  const nf_flow_desc& d = desc;
+  const int D = d.event_dim, nh = d.num_hidden, nlin = nh + 1;
+  const int act = d.activation == NF_ACT_RELU ? 1 : 2;
+  const RqsConst rc = make_rqs_const(d);
+  const float inv_n = 1.f / (float)rows_global, gld = -inv_n;
+  // scratch per row: hidden activations, theta, d theta, two gradient buffers, one log-det column
+  const int gwidth = std::max(act_width, D);
+  const size_t per_row = ((size_t)nh * act_width + 2 * (size_t)param_width + 2 * (size_t)gwidth) * sizeof(float);
+  long long cap = (long long)(((size_t)4 << 30) / per_row);
+  cap = std::max<long long>(128, cap / 128 * 128);
+  const long long want = std::min(rows, cap);
+  if (want > b.scratch_rows) {
+    hipFree(b.d_scratch);
+    b.d_scratch = nullptr;
+    b.scratch_rows = 0;
+    NF_HIP(hipMalloc(&b.d_scratch, per_row * (size_t)want));
+    b.scratch_rows = want;
+  }
+  NF_HIP(hipMemsetAsync(b.d_grad, 0, b.n_weights * sizeof(float), stream));
+  NF_HIP(hipMemsetAsync(grad_canon, 0, weight_count * sizeof(float), stream));
+  hipLaunchKernelGGL(base_grad_kernel, dim3(grid_for(rows * D)), dim3(256), 0, stream, v, g, rows * D, d.base, inv_n);
+
+  const long long R = b.scratch_rows;
+  float* acts = b.d_scratch;                                   // [nh][R][act_width]
+  float* th = acts + (size_t)nh * R * act_width;               // [R][param_width]
+  float* dth = th + (size_t)R * param_width;
+  float* ga = dth + (size_t)R * param_width;                   // [R][gwidth]
+  float* gb = ga + (size_t)R * gwidth;
+  for (long long r0 = 0; r0 < rows; r0 += R) {
+    const long long n = std::min(R, rows - r0);
+    float* gc = g + r0 * D;
+    for (int l = 0; l < d.num_layers; ++l) {  // the layer log_prob applied last comes first
+      const int par = (d.first_mask_parity + l) & 1;
+      const Linear* Ls = &linears[(size_t)l * nlin];
+      const float* vc = b.d_tape + ((size_t)l * b.tape_rows + r0) * D;  // this layer's input
+      // 1. conditioner on the recorded input
+      const float* a = vc;
+      int lda = D;
+      for (int j = 0; j < nlin; ++j) {
+        float* dst = j == nlin - 1 ? th : acts + (size_t)j * R * act_width;
+        NF_TRY(launch_gemm(a, lda, d_weights + Ls[j].w_off, d_weights + Ls[j].b_off, dst, Ls[j].N, (int)n, Ls[j].N,
+                           Ls[j].K, j == nlin - 1 ? 0 : act, stream));
+        a = dst;
+        lda = Ls[j].N;
+      }
+      // 3. transform backward
+      if (d.kind == NF_KIND_AFFINE_MASKED) {
+        hipLaunchKernelGGL(affine_masked_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, vc, gc, th, dth, n, D,
+                           par, gld);
+      } else {
+        const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+        const dim3 grid(grid_for(n * Dt));
+        if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else hipLaunchKernelGGL((rqs_masked_bwd_kernel<32>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
+      }
+      NF_HIP(hipGetLastError());
+      // 4. MLP backward
+      const float* gcur = dth;
+      for (int j = nlin - 1; j >= 0; --j) {
+        const Linear& L = Ls[j];
+        const float* ain = j == 0 ? vc : acts + (size_t)(j - 1) * R * act_width;
+        const int lain = j == 0 ? D : Ls[j - 1].N;
+        NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_partials, b.partial_floats,
+                             stream));
+        NF_TRY(accumulate_tn(nullptr, 0, gcur, L.N, n, 1, L.N, b.d_grad + L.b_off, b.d_partials, b.partial_floats,
+                             stream));
+        float* gprev = (gcur == ga) ? gb : ga;
+        NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gprev, L.K, (int)n, L.K,
+                           L.N, 0, stream));
+        if (j > 0) {
+          hipLaunchKernelGGL(act_grad_kernel, dim3(grid_for(n * L.K)), dim3(256), 0, stream, gprev, ain, n * L.K, act);
+        } else {
+          // rows of W_1 that belong to transformed dims are structural zeros: nothing flows there
+          hipLaunchKernelGGL(add_kernel, dim3(grid_for(n * D)), dim3(256), 0, stream, gc, gprev, n * D);
+        }
+        gcur = gprev;
+      }
+      NF_HIP(hipGetLastError());
+    }
+  }
+  hipLaunchKernelGGL(scatter_grad_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream, b.d_grad,
+                     b.d_canon_index, grad_canon, (long long)b.n_weights);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+}  // namespace generic
+}  // namespace nf

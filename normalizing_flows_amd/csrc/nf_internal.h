@@ -173,6 +173,16 @@ struct Linear {
   size_t w_off = 0, b_off = 0;  // offsets into d_weights, floats
   size_t x3_off = 0;            // offset into d_wx3 (bf16 units); valid when Plan::x3
 };
+struct RqsConst {
+  int K;
+  float range_min, range_max, min_bin, min_slope, slope_offset;
+};
+RqsConst make_rqs_const(const nf_flow_desc& d);
+int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K,
+                int act, hipStream_t stream);
+int launch_transform(const nf_flow_desc& d, float* y, float* ld, const float* params, long long n, int par,
+                     int inverse_op, const RqsConst& rc, hipStream_t stream);
+
 struct Plan {
   nf_flow_desc desc;
   std::vector<Linear> linears;  // [layer][linear]
@@ -185,7 +195,32 @@ struct Plan {
   bool x3 = false;
   unsigned short* d_wx3 = nullptr;
   std::vector<float> host_weights;  // what d_weights holds (after masking / pruning)
+  std::vector<int> canon_index;     // per d_weights entry: index into the packed (canonical) vector, -1 = zero
   int set_x3(bool on);
+  // ---- training (nf_generic_bwd.hip): masked kinds, chain in the log_prob direction ---------------
+  struct Backward {
+    bool ready = false;
+    size_t n_weights = 0;            // floats in d_weights
+    float* d_grad = nullptr;         // d(NLL)/d(d_weights), same layout
+    float* d_wT = nullptr;           // every Linear's W transposed, [N][K], at wT_off
+    std::vector<size_t> wT_off;
+    int* d_canon_index = nullptr;
+    float* d_zero = nullptr;         // zero bias for the data-gradient GEMMs
+    float* d_partials = nullptr;     // weight-gradient partial sums, one slab per row chunk
+    size_t partial_floats = 0;
+    float* d_scratch = nullptr;
+    long long scratch_rows = 0;
+    float* d_tape = nullptr;         // [num_layers][tape_rows][D]: every layer's input from the forward walk
+    long long tape_rows = 0;
+  } bwd;
+  bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
+  int ensure_tape(long long rows);
+  int prepare_backward();            // after build(): index map, transposes, buffers
+  int refresh_from_canonical(const float* d_canon, hipStream_t stream);  // after an optimiser step
+  // z [rows, D]: the chain's output of a walk() recorded with record_tape.  g [rows, D]: scratch.
+  // grad_canon [weight_count]: receives d(NLL)/d(packed weights), NLL = -mean over rows_global.
+  int backward(const float* z, float* g, long long rows, long long rows_global, float* grad_canon,
+               size_t weight_count, hipStream_t stream);
   int build(const nf_flow_desc& d, const float* packed);
   void release();
   int ensure_scratch(long long rows);

@@ -700,3 +700,139 @@ def a_nll_and_grad(params, flips, y, dtype=np.float64):
         grads[l] = lg[::-1]
         G = _a_join(G1 + g, G2 * einv, flip)
     return float(nll), grads
+
+
+# --------------------------------------------------------------------------
+# gradient of the NLL for the masked kinds in general (any D, widths, affine or spline) --
+# what jax.grad(loss_fn) returns in src/real_nvp_toy_densities.py:164-173,
+# src/maf_toy_densities.py:167-176, src/maf_mnist.py:159-168.  The spline's own Jacobian is taken
+# by complex-step differentiation of the rational-quadratic formula (exact to rounding in float64,
+# and independent of the hand-derived partials in the HIP kernel).
+# --------------------------------------------------------------------------
+def _rqs_bin_formula(x, xl, xr, yl, yr, sl, sr):
+    w = xr - xl
+    h = yr - yl
+    delta = h / w
+    z = (x - xl) / w
+    zz = z * z
+    z1mz = z - zz
+    omz2 = (1.0 - z) ** 2
+    st = sr + sl - 2.0 * delta
+    y = yl + h * (delta * zz + sl * z1mz) / (delta + st * z1mz)
+    ld = 2.0 * np.log(delta) + np.log(sr * zz + 2.0 * delta * z1mz + sl * omz2) - 2.0 * np.log(delta + st * z1mz)
+    return y, ld
+
+
+def rqs_param_grads(x, raw, gy, gld, spec: FlowSpec):
+    """x [n, T] inputs of the transformed dims, raw [n, T, 3K+1] conditioner outputs, gy [n, T] =
+    dL/dy, gld (scalar) = dL/d(logdet).  Returns (dL/draw [n, T, 3K+1], dL/dx [n, T])."""
+    K = spec.num_bins
+    xp, yp, sl = rqs_knots(raw, spec.range_min, spec.range_max, spec.min_bin_size, spec.min_knot_slope, np.float64)
+    x = np.asarray(x, np.float64)
+    k = _pick_bin(x, xp)
+    ins = [x, _take(xp, k), _take(xp, k + 1), _take(yp, k), _take(yp, k + 1), _take(sl, k), _take(sl, k + 1)]
+    h = 1e-30
+    g7 = []
+    for j in range(7):
+        pert = [a.astype(np.complex128) for a in ins]
+        pert[j] = pert[j] + 1j * h
+        y, ld = _rqs_bin_formula(*pert)
+        g7.append(gy * (y.imag / h) + gld * (ld.imag / h))
+    below = x <= xp[..., 0]
+    above = x >= xp[..., -1]
+    tail = below | above
+    s_tail = np.where(below, sl[..., 0], sl[..., -1])
+    edge = np.where(below, xp[..., 0], xp[..., -1])
+    gx = np.where(tail, gy * s_tail, g7[0])
+    g_xp = np.zeros_like(xp)
+    g_yp = np.zeros_like(yp)
+    g_sl = np.zeros_like(sl)
+    inside = (~tail).astype(np.float64)
+
+    def scatter(dst, idx, val):
+        np.put_along_axis(dst, idx[..., None], np.take_along_axis(dst, idx[..., None], -1) + val[..., None], -1)
+
+    scatter(g_xp, k, g7[1] * inside)
+    scatter(g_xp, k + 1, g7[2] * inside)
+    scatter(g_yp, k, g7[3] * inside)
+    scatter(g_yp, k + 1, g7[4] * inside)
+    scatter(g_sl, k, g7[5] * inside)
+    scatter(g_sl, k + 1, g7[6] * inside)
+    g_tail = (gy * (x - edge) + gld / s_tail) * tail
+    scatter(g_sl, np.where(below, 0, K) * np.ones_like(k), g_tail)
+    # knots -> bin sizes (the first and last knot are constants) -> softmax logits
+    c = (spec.range_max - spec.range_min) - K * spec.min_bin_size
+
+    def sizes_to_logits(g_pos, logits):
+        g_size = np.zeros(g_pos.shape[:-1] + (K,))
+        g_size[..., :K - 1] = np.cumsum(g_pos[..., 1:K][..., ::-1], -1)[..., ::-1]
+        s = _softmax(np.asarray(logits, np.float64))
+        return c * s * (g_size - np.sum(g_size * s, -1, keepdims=True))
+
+    raw = np.asarray(raw, np.float64)
+    offset = np.log(np.exp(1.0 - spec.min_knot_slope) - 1.0)
+    g_raw = np.concatenate([sizes_to_logits(g_xp, raw[..., :K]), sizes_to_logits(g_yp, raw[..., K:2 * K]),
+                            g_sl / (1.0 + np.exp(-(raw[..., 2 * K:] + offset)))], -1)
+    return g_raw, gx
+
+
+def flow_nll_and_grad(spec: FlowSpec, x):
+    """(nll, grads) of -mean(log_prob) for a masked-affine or masked-spline FlowSpec in float64;
+    grads[l] = [(dW, db), ...] shaped like spec.layers[l].  relu'(0) = 0."""
+    dtype = np.float64
+    x = np.asarray(x, dtype)
+    n, D = x.shape
+    L = len(spec.layers)
+    P = 3 * spec.num_bins + 1
+    tape = []
+    v = x
+    total_ld = np.zeros(n, dtype)
+    for l in reversed(range(L)):
+        mask = spec.masks[l]
+        masked = np.where(mask, v, 0.0)
+        acts, pre, a = [masked], [], masked
+        for W, b in spec.layers[l][:-1]:
+            z = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+            pre.append(z)
+            a = relu(z)
+            acts.append(a)
+        W, b = spec.layers[l][-1]
+        out = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
+        y, ld = coupling_layer(spec, l, v, False, dtype)
+        tape.append((l, v, acts, pre, out))
+        total_ld = total_ld + ld
+        v = y
+    z_final = v
+    nll = float(-np.mean(base_log_prob(spec, z_final, dtype) + total_ld))
+    grads = [None] * L
+    G = z_final / n if spec.base == "normal" else np.zeros_like(z_final)
+    gld = -1.0 / n
+    for l, v_in, acts, pre, out in reversed(tape):
+        mask = spec.masks[l]
+        t_idx = np.nonzero(~mask)[0]
+        if spec.kind == "affine":
+            ls = out[:, 1:2]
+            e = np.exp(ls)
+            Gt = G[:, t_idx]
+            g_out = np.concatenate([Gt.sum(-1, keepdims=True),
+                                    (Gt * v_in[:, t_idx] * e).sum(-1, keepdims=True) + gld * len(t_idx)], -1)
+            gx_t = Gt * e
+        else:
+            raw = out.reshape(n, D, P)[:, t_idx, :]
+            g_raw, gx_t = rqs_param_grads(v_in[:, t_idx], raw, G[:, t_idx], gld, spec)
+            g_out = np.zeros((n, D, P))
+            g_out[:, t_idx, :] = g_raw
+            g_out = g_out.reshape(n, D * P)
+        lin = spec.layers[l]
+        lg, g = [], g_out
+        for j in reversed(range(len(lin))):
+            W = np.asarray(lin[j][0], dtype)
+            lg.append((acts[j].T @ g, g.sum(0)))
+            g = g @ W.T
+            if j > 0:
+                g = g * (pre[j - 1] > 0)
+        grads[l] = lg[::-1]
+        Gn = np.where(mask, G + g, 0.0)
+        Gn[:, t_idx] = gx_t
+        G = Gn
+    return nll, grads

@@ -345,3 +345,46 @@ def test_variant_a_gradient_restatement_against_finite_differences():
                     old, eps = float(arr[idx]), 1e-6
                     fd = (f(old + eps) - f(old - eps)) / (2 * eps)
                     assert abs(fd - grads[l][j][which][idx]) <= 1e-7 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("kind,D,hidden,K", [("rqs", 2, (16, 16), 4), ("rqs", 5, (12,), 3), ("affine", 4, (8, 8), 0),
+                                             ("rqs", 2, (64, 64), 12)])
+def test_flow_gradient_matches_finite_differences(kind, D, hidden, K):
+    """KAT 10: flow_nll_and_grad (what jax.grad(loss_fn) returns for the masked flows, spline
+    Jacobian by complex step) against central differences of the oracle NLL in float64.
+    Inputs reach beyond the spline range, so the linear tails take part."""
+    rng = np.random.default_rng(D * 10 + K)
+    if kind == "rqs":
+        spec = O.make_rqs_spec(3, event_size=D, hidden=hidden, num_bins=K, range_min=-3.0, range_max=3.0,
+                               final_std=0.3)
+    else:
+        spec = O.make_affine_spec(3, event_size=D, hidden=hidden, final_std=0.2)
+    spec.layers = [[(np.asarray(W, np.float64), np.asarray(b, np.float64) + 0.01 * rng.standard_normal(b.shape))
+                    for W, b in lay] for lay in spec.layers]
+    x = rng.standard_normal((200, D)) * 2.0
+    nll, g = O.flow_nll_and_grad(spec, x)
+    assert abs(nll - O.nll(spec, x)) < 1e-12
+    for l in range(3):
+        for j, (W, b) in enumerate(spec.layers[l]):
+            for which, arr in ((0, W), (1, b)):
+                scale = np.abs(g[l][j][which]).max()
+                for _ in range(4):
+                    idx = tuple(rng.integers(0, s) for s in arr.shape)
+                    old, eps = arr[idx], 1e-6
+                    arr[idx] = old + eps
+                    fp = O.nll(spec, x)
+                    arr[idx] = old - eps
+                    fm = O.nll(spec, x)
+                    arr[idx] = old
+                    assert abs((fp - fm) / (2 * eps) - g[l][j][which][idx]) <= 1e-6 * max(scale, 1e-3), (l, j, which, idx)
+
+
+def test_flow_gradient_agrees_with_the_affine_restatement():
+    spec = O.make_affine_spec(4, final_std=0.05)
+    x = O.make_inputs("banana", 500)
+    nll_a, g_a = O.affine_nll_and_grad(spec, x)
+    nll_b, g_b = O.flow_nll_and_grad(spec, x)
+    assert abs(nll_a - nll_b) < 1e-12
+    for la, lb in zip(g_a, g_b):
+        for (wa, ba), (wb, bb) in zip(la, lb):
+            assert np.allclose(wa, wb, rtol=1e-10, atol=1e-14) and np.allclose(ba, bb, rtol=1e-10, atol=1e-14)

@@ -1,0 +1,159 @@
+"""GPU parity of the general training step (nf_generic_bwd.hip): d NLL / d weights of the masked
+coupling kinds -- affine and rational-quadratic spline, any event size and conditioner widths,
+including the fused spline kernel's flows -- against the oracle's float64 reverse mode
+(oracle.flows_np.flow_nll_and_grad, itself checked against finite differences in
+tests/test_oracle_kat.py).  Tolerance per tensor: 2e-4 of its largest entry (float32 accumulation
+over the batch), as for the fused affine backward in tests/test_parity_gpu.py.
+
+Reference: jax.grad(loss_fn) + optax.adam in `update` (src/maf_toy_densities.py:167-176,
+src/maf_mnist.py:159-168, src/real_nvp_toy_densities.py:164-173)."""
+import numpy as np
+import pytest
+
+from oracle import flows_np as O
+from test_parity_gpu import _flat, affine_flow, assert_close, rqs_flow
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nfa(nf_lib):
+    from normalizing_flows_amd import _lib, flow
+    _lib.require_device()
+    return flow
+
+
+def check_grads(f, spec, x, tol=2e-4):
+    nll, grads = f.nll_grad(x)
+    rnll, rgrads = O.flow_nll_and_grad(spec, x)
+    assert abs(nll - rnll) <= 2e-5 * max(1.0, abs(rnll)), (nll, rnll)
+    for l in range(len(spec.layers)):
+        for j in range(len(spec.layers[l])):
+            for which in (0, 1):
+                got, ref = grads[l][j][which], rgrads[l][j][which]
+                assert got.shape == ref.shape
+                scale = max(np.abs(ref).max(), 1e-6)
+                assert np.abs(got - ref).max() <= tol * scale, (l, j, which, np.abs(got - ref).max(), scale)
+    return grads, rgrads
+
+
+@pytest.mark.parametrize("K,L,parity,rows,density", [(12, 8, 1, 4096, "banana"), (12, 2, 0, 1000, "gaussian_blobs"),
+                                                     (8, 3, 1, 33, "energy2"), (4, 5, 0, 2000, "banana")])
+def test_spline_2d_gradient(nfa, K, L, parity, rows, density):
+    """BASELINE.json configs[2]'s flow (the fused spline kernel's handles train through the plan).
+    banana leaves [-8, 8]: the linear tails' gradients take part."""
+    spec = O.make_rqs_spec(L, num_bins=K, final_std=0.05, first_parity=parity)
+    f = rqs_flow(nfa, spec, parity)
+    assert f.kernel_name == "rqs2d_h64_mfma"
+    x = O.make_inputs(density, rows, seed=K + L)
+    grads, _ = check_grads(f, spec, x)
+    P = 3 * K + 1
+    for l in range(L):
+        # the masked input's row of the first Linear and the pass-through dim's parameter columns get exactly zero
+        masked_row = 0 if spec.masks[l][1] else 1
+        assert np.all(grads[l][0][0][masked_row] == 0)
+        passthrough = 0 if spec.masks[l][0] else 1
+        assert np.all(grads[l][-1][0][:, passthrough * P:(passthrough + 1) * P] == 0)
+        assert np.all(grads[l][-1][1][passthrough * P:(passthrough + 1) * P] == 0)
+
+
+@pytest.mark.parametrize("D,hidden,K,L,parity,lo,hi", [(6, (32, 32), 4, 3, 0, -3.0, 3.0), (5, (24,), 8, 2, 1, -4.0, 4.0),
+                                                       (3, (40, 20, 36), 3, 2, 1, -2.0, 2.0), (4, (16,), 16, 2, 0, -5.0, 5.0)])
+def test_spline_general_gradient(nfa, D, hidden, K, L, parity, lo, hi):
+    spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=lo, range_max=hi, final_std=0.2,
+                           first_parity=parity)
+    f = rqs_flow(nfa, spec, parity)
+    assert f.kernel_name == "generic_gemm"
+    x = np.random.default_rng(D + K).standard_normal((1500, D)).astype(np.float32) * 2.0
+    check_grads(f, spec, x)
+
+
+@pytest.mark.parametrize("D,hidden,L,parity", [(4, (64, 64), 4, 1), (7, (16, 16), 2, 1), (2, (32, 32), 4, 0), (5, (33,), 3, 0)])
+def test_affine_general_gradient(nfa, D, hidden, L, parity):
+    spec = O.make_affine_spec(L, event_size=D, hidden=hidden, final_std=0.05, first_parity=parity)
+    f = affine_flow(nfa, spec, parity)
+    assert f.kernel_name == "generic_gemm"
+    x = np.random.default_rng(D * 10 + L).standard_normal((3001, D)).astype(np.float32) * 1.5
+    check_grads(f, spec, x)
+
+
+def test_general_gradient_matches_the_fused_backward(nfa):
+    """Same model through both backward implementations: D = 2 / (64, 64) is the fused kernel's,
+    the general path is reached with a third hidden layer of identity-free shape -- not the same
+    model; so both are held to the oracle on their own models, and here only the oracle's two
+    restatements are tied together on the fused kernel's model."""
+    spec = O.make_affine_spec(3, final_std=0.05)
+    x = O.make_inputs("banana", 2000)
+    _, g_a = O.affine_nll_and_grad(spec, x)
+    _, g_b = O.flow_nll_and_grad(spec, x)
+    assert np.abs(_flat(g_a) - _flat(g_b)).max() <= 1e-12
+
+
+def test_mnist_shape_gradient(nfa):
+    """BASELINE.json configs[4] shapes (784-D, MLP 512x3, K = 8 on [0, 1], Uniform base), 2 layers, 64 rows."""
+    x = O.make_inputs("mnist_like", 64)
+    spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0, range_max=1.0,
+                           base="uniform01", final_std=0.1)
+    f = rqs_flow(nfa, spec)
+    check_grads(f, spec, x, tol=5e-4)   # 392 transformed dims feed every conditioner weight
+
+
+def test_spline_adam_steps_and_fused_kernel_follows(nfa):
+    """Three `update` steps on the configs[2] flow against optax.adam restated in float64; afterwards
+    the fused kernel (log_prob) and the general path (training) must agree on the new weights."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(4, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    opt = training.adam(1e-3)
+    p = _flat([[(W.astype(np.float64), b.astype(np.float64)) for W, b in layer] for layer in spec.layers])
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for step in range(1, 4):
+        x = O.make_inputs("gaussian_blobs", 2048, seed=50 + step)
+        loss = f.train_step(x, opt)
+        cur = O.make_rqs_spec(4, final_std=0.05)
+        cur.layers = f.unpack_weights(p.astype(np.float64))
+        rl, rg = O.flow_nll_and_grad(cur, x)
+        assert abs(loss - rl) <= 2e-5 * max(1.0, abs(rl)), (step, loss, rl)
+        p, m, v = O.adam_reference(p, _flat(rg), m, v, step, 1e-3)
+    got = _flat(f.get_weights())
+    assert np.abs(got - p).max() <= 0.05 * 3 * 1e-3, np.abs(got - p).max()
+    assert np.abs(got - _flat(spec.layers)).max() > 1e-3
+    new_spec = O.make_rqs_spec(4, final_std=0.05)
+    new_spec.layers = f.get_weights()
+    x = O.make_inputs("gaussian_blobs", 3000, seed=7)
+    ref = O.log_prob(new_spec, x)
+    e32 = np.abs(O.log_prob(new_spec, x, np.float32) - ref).max()
+    assert f.kernel_name == "rqs2d_h64_mfma"
+    assert_close(f.log_prob(x), ref, "fused spline log_prob after training", 4 * e32)
+    assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
+    # new weights from the host restart the optimiser state and reach both representations
+    f.set_weights(spec.layers)
+    assert_close(f.log_prob(x), O.log_prob(spec, x), "after set_weights", 4 * e32)
+    check_grads(f, spec, x)
+
+
+def test_spline_training_reduces_nll(nfa):
+    """The reference's maf_toy_densities.py loop in miniature: zero-initialised final Linear
+    (identity flow), Adam, gaussian_blobs."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(4, final_std=0.0)
+    f = rqs_flow(nfa, spec)
+    opt = training.adam(2e-3)
+    x_eval = O.make_inputs("gaussian_blobs", 8192, seed=999)
+    before = f.nll(x_eval)
+    for step in range(80):
+        f.train_step(O.make_inputs("gaussian_blobs", 2048, seed=step), opt, want_nll=False)
+    after = f.nll(x_eval)
+    assert np.isfinite(after) and after < before - 0.3, (before, after)
+
+
+def test_split_kind_on_the_general_path_still_refuses(nfa):
+    from normalizing_flows_amd import _lib
+    from normalizing_flows_amd._lib import NFError
+    params, _ = O.make_a_params(2, sizes=(2, 8, 4))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=4, num_layers=2, hidden=(8,),
+                         activation=_lib.ACT_LEAKY_RELU)
+    f = nfa.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
+    with pytest.raises(NFError):
+        f.nll_grad(np.zeros((8, 4), np.float32))
