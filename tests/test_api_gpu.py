@@ -303,3 +303,51 @@ def test_real_nvp_py_training_loop(distrax):
     for batch in densities.make_dataset_energy_2(seed=231, batch_size=128, num_batches=300):
         nll, params = R.sgd_update(params, fns_config, batch, learning_rate=1e-2)
     assert R.loss(params, fns_config, valid) < first - 0.05
+
+
+def test_maf_toy_training_through_the_distrax_surface(distrax):
+    """`update` of src/maf_toy_densities.py:167-176 (jax.grad(loss_fn) + optax.adam) with the spline
+    model built as the script builds it; gradients keyed like the haiku parameter dict."""
+    from normalizing_flows_amd import densities, training
+    rng = np.random.default_rng(43)
+    model, layers = make_flow_model_rqs(distrax, (2,), 4, [64, 64], 12, -8.0, 8.0, "normal", rng, 0.02)
+    spec0 = spec_of(layers, "rqs", 2, num_bins=12, range_min=-8.0, range_max=8.0)
+    valid = next(densities.make_dataset_gaussian_blobs(seed=2235, batch_size=4096, num_batches=1))
+    loss0, grads = training.value_and_grad(model, valid)
+    rl, rg = O.flow_nll_and_grad(spec0, valid)
+    assert abs(loss0 - rl) <= 2e-5 * max(1.0, abs(rl))
+    assert sorted(grads) == sorted(distrax.layers_to_haiku_params([l.conditioner.linears for l in layers]))
+    for name, (l, j) in {"mlp/~/linear_0": (0, 0), "mlp_2/~/linear_1": (2, 1), "linear_3": (3, 2)}.items():
+        for key, which in (("w", 0), ("b", 1)):
+            ref = rg[l][j][which]
+            assert np.abs(grads[name][key] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), (name, key)
+    optimizer = training.adam(2e-3)
+    before = model.nll(valid)
+    for batch in densities.make_dataset_gaussian_blobs(seed=2123, batch_size=2048, num_batches=60):
+        training.update(model, optimizer, batch, want_loss=False)
+    after = model.nll(valid)
+    assert np.isfinite(after) and after < before - 0.2, (before, after)
+    training.sync_params(model)
+    spec1 = spec_of(layers, "rqs", 2, num_bins=12, range_min=-8.0, range_max=8.0)
+    assert abs(O.nll(spec1, valid) - after) <= 2e-5 * max(1.0, abs(after))
+    s = model.sample(seed=3, sample_shape=2000)        # the trained flow samples through the fused kernel
+    assert np.isfinite(s).all()
+
+
+def test_maf_mnist_training_step_shapes(distrax):
+    """One `update` of src/maf_mnist.py:159-168 at its shapes (28x28x1 events, Uniform base)."""
+    from normalizing_flows_amd import training
+    rng = np.random.default_rng(44)
+    model, layers = make_flow_model_rqs(distrax, (28, 28, 1), 2, [512, 512, 512], 8, 0.0, 1.0, "uniform", rng, 0.05)
+    x = O.make_inputs("mnist_like", 64).reshape(64, 28, 28, 1)
+    spec = spec_of(layers, "rqs", 784, num_bins=8, range_min=0.0, range_max=1.0, base="uniform01")
+    loss, grads = training.value_and_grad(model, x)
+    rl, rg = O.flow_nll_and_grad(spec, x.reshape(64, 784))
+    assert abs(loss - rl) <= 2e-5 * max(1.0, abs(rl))
+    ref = rg[1][3][0]
+    assert grads["linear_1"]["w"].shape == ref.shape == (512, 784 * 25)
+    assert np.abs(grads["linear_1"]["w"] - ref).max() <= 5e-4 * np.abs(ref).max()
+    before = model.nll(x)
+    for _ in range(5):
+        training.update(model, training.adam(1e-4), x, want_loss=False)
+    assert model.nll(x) < before
