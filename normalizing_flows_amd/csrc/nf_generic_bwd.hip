@@ -10,8 +10,8 @@
 //   2. (nothing to invert: unlike the affine map, a spline's float32 inverse can be off by
 //      1e-4 where |dx/dy| is large, and the parameter gradients inherit that error -- measured)
 //   3. transform backward: d theta and dL/dx of the transformed dims from dL/dy and dL/d(logdet)
-//   4. MLP backward: dW_j += a_{j-1}^T g (rows on the MFMA k dimension, fixed-order partial sums),
-//      db_j += column sums, g <- (g W_j^T) * act'(a_{j-1}) (the forward GEMM kernels on a
+//   4. MLP backward: [dW_j; db_j] += [a_{j-1}, 1]^T g (rows on the MFMA k dimension, fixed-order
+//      partial sums), g <- (g W_j^T) * act'(a_{j-1}) (the forward GEMM kernels on a
 //      transposed copy of W_j), and finally dL/dx of the pass-through dims += g W_1^T.
 // Gradients are accumulated in the plan's own weight layout (masked rows / pruned columns are
 // structural zeros there) and scattered to the canonical layout at the end.
@@ -292,9 +292,11 @@ __global__ __launch_bounds__(256) void rqs_masked_bwd_kernel(const float* __rest
   }
 }
 
-// ---- weight gradient: C[K, N] (+)= A[rows, K]^T B[rows, N], rows on the MFMA k dimension --------
-// One workgroup: a 32 x 32 tile of C over one chunk of rows, split between its 4 waves and added
-// through LDS in a fixed order.  A == nullptr: a column of ones (K = 1): column sums, for the biases.
+// ---- weight and bias gradient: [dW; db] (+)= [A, 1]^T B, rows on the MFMA k dimension ----------
+// A [rows, K] is extended by a column of ones (index K), so the bias gradient (column sums of B) is
+// row K of the same product.  One workgroup: a 32 x 32 tile of the (K+1) x N result over one chunk
+// of rows, split between its 4 waves (8 row pairs in flight per wave) and added through LDS in a
+// fixed order.
 __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict__ A, int lda,
                                                          const float* __restrict__ B, int ldb,
                                                          float* __restrict__ partial, long long rows,
@@ -305,36 +307,54 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
   const int k0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
   const long long c0 = (long long)blockIdx.y * chunk_rows;
   const long long c1 = std::min(rows, c0 + chunk_rows);
-  long long per = ((c1 - c0 + 3) / 4 + 1) & ~1LL;  // even, so that a wave's 2-row steps stay aligned
+  const long long per = ((c1 - c0 + 3) / 4 + 1) & ~1LL;  // even: a wave's 2-row steps stay aligned
   const long long m0 = c0 + wave * per, m1 = std::min(c1, m0 + per);
-  const bool kin = k0 + i < K, nin = n0 + i < N;
+  const int kcol = k0 + i;
+  const bool kin = kcol < K, kone = kcol == K, nin = n0 + i < N;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (long long m = m0; m < m1; m += 2) {
-    const long long row = m + h;
-    const bool ok = row < m1;
-    const float a = (ok && kin) ? (A ? A[row * lda + k0 + i] : 1.f) : 0.f;
-    const float b = (ok && nin) ? B[row * ldb + n0 + i] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  for (long long m = m0; m < m1; m += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long row = m + 2 * u + h;
+      const bool ok = row < m1;
+      a[u] = ok ? (kin ? A[row * lda + kcol] : (kone ? 1.f : 0.f)) : 0.f;
+      b[u] = (ok && nin) ? B[row * ldb + n0 + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.y * K * N;
+  float* out = partial + (size_t)blockIdx.y * (K + 1) * N;
   for (int q = threadIdx.x; q < 1024; q += 256) {
     const int r = q >> 6, l = q & 63;
     const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), nn = n0 + (l & 31);
-    if (kk < K && nn < N) out[(size_t)kk * N + nn] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+    if (kk <= K && nn < N) out[(size_t)kk * N + nn] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
   }
 }
 
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int nchunks, size_t count,
-                                                        float* __restrict__ grad) {
-  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < count; q += (size_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * count + q];
-    grad[q] += s;
+// 64 outputs per workgroup; its four waves each add every fourth chunk slab (in order), LDS joins the
+// four partial sums in a fixed order.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int nchunks, size_t kn,
+                                                        size_t n, float* __restrict__ grad_w,
+                                                        float* __restrict__ grad_b) {
+  __shared__ float red[4][64];
+  const size_t count = kn + n;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t q = (size_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (q < count)
+    for (int c = grp; c < nchunks; c += 4) s += partial[(size_t)c * count + q];
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && q < count) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (q < kn) grad_w[q] += t;
+    else grad_b[q - kn] += t;
   }
 }
 
@@ -342,20 +362,23 @@ static int grid_for(long long total, int cap = 8192) {
   return (int)std::max<long long>(1, std::min<long long>(cap, (total + 255) / 256));
 }
 
-// grad[K*N] += A^T B
-static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long long rows, int K, int N, float* grad,
-                         float* partials, size_t partial_floats, hipStream_t stream) {
-  const size_t count = (size_t)K * N;
-  int nchunks = (int)std::min<long long>(64, std::max<long long>(1, (rows + 2047) / 2048));
+// grad_w[K*N] += A^T B, grad_b[N] += column sums of B
+static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long long rows, int K, int N,
+                         float* grad_w, float* grad_b, float* partials, size_t partial_floats, hipStream_t stream) {
+  const size_t count = (size_t)(K + 1) * N;
+  const int tiles_k = (K + 1 + 31) / 32, tiles_n = (N + 31) / 32;
+  // enough row chunks to fill the chip even when the result has few tiles (64 x 64: four)
+  long long want = std::max<long long>(1, 2048 / ((long long)tiles_k * tiles_n));
+  want = std::min<long long>(want, std::max<long long>(1, rows / 256));
+  int nchunks = (int)std::min<long long>(256, want);
   nchunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)nchunks, partial_floats / count));
   long long chunk_rows = (rows + nchunks - 1) / nchunks;
   chunk_rows = (chunk_rows + 1) & ~1LL;
   nchunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-  const int tiles_k = (K + 31) / 32, tiles_n = (N + 31) / 32;
   hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, nchunks), dim3(256), 0, stream, A, lda, B, ldb,
                      partials, rows, chunk_rows, K, N, tiles_n);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid_for((long long)count, 2048)), dim3(256), 0, stream, partials, nchunks,
-                     count, grad);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, partials, nchunks,
+                     (size_t)K * N, (size_t)N, grad_w, grad_b);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
@@ -385,14 +408,14 @@ int Plan::prepare_backward() {
   for (const Linear& L : linears) {
     b.wT_off.push_back(wt);
     wt += ((size_t)L.K * L.N + 3) / 4 * 4;
-    biggest = std::max(biggest, (size_t)L.K * L.N);
+    biggest = std::max(biggest, (size_t)(L.K + 1) * L.N);
     widest = std::max(widest, std::max(L.K, L.N));
   }
   NF_HIP(hipMalloc(&b.d_wT, wt * sizeof(float)));
   NF_HIP(hipMalloc(&b.d_zero, (size_t)widest * sizeof(float)));
   NF_HIP(hipMemset(b.d_zero, 0, (size_t)widest * sizeof(float)));
-  // up to 16 row-chunk slabs of the largest Linear, at most 512 MiB
-  b.partial_floats = std::max(biggest, std::min<size_t>(biggest * 16, ((size_t)512 << 20) / sizeof(float)));
+  // up to 256 row-chunk slabs of the largest Linear, at most 512 MiB
+  b.partial_floats = std::max(biggest, std::min<size_t>(biggest * 256, ((size_t)512 << 20) / sizeof(float)));
   NF_HIP(hipMalloc(&b.d_partials, b.partial_floats * sizeof(float)));
   for (size_t q = 0; q < linears.size(); ++q) {
     const Linear& L = linears[q];
@@ -503,10 +526,8 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
         const Linear& L = Ls[j];
         const float* ain = j == 0 ? vc : acts + (size_t)(j - 1) * R * act_width;
         const int lain = j == 0 ? D : Ls[j - 1].N;
-        NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_partials, b.partial_floats,
-                             stream));
-        NF_TRY(accumulate_tn(nullptr, 0, gcur, L.N, n, 1, L.N, b.d_grad + L.b_off, b.d_partials, b.partial_floats,
-                             stream));
+        NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
+                             b.partial_floats, stream));
         float* gprev = (gcur == ga) ? gb : ga;
         NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gprev, L.K, (int)n, L.K,
                            L.N, 0, stream));

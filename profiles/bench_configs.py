@@ -121,3 +121,28 @@ if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densiti
         print(json.dumps({"config": f"train step (fwd + bwd + Adam) variant B L=8 banana batch=2^{lg}", "ms_stream": ms,
                           "ms_wall": wall, "samples_per_s": rows / ms * 1e3,
                           "TFLOPs_at_4x_forward": rows * 4 * 69632 / ms / 1e9}))
+
+if "trainc" in which:   # `update` of src/maf_toy_densities.py:167-176 (spline flow, general backward)
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(8, final_std=0.05)
+    cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), rqs_bins=12,
+                          rqs_range_min=-8.0, rqs_range_max=8.0)
+    f = flow.CouplingFlow(cfg, spec.layers)
+    opt = training.adam(1e-4)
+    for lg in (7, 12, 17, 20):
+        rows = 1 << lg
+        xd = flow.DeviceArray.from_numpy(O.make_inputs("gaussian_blobs", rows))
+        for _ in range(3):
+            f.train_step(xd, opt, want_nll=False)
+        f.synchronize()
+        steps = 20 if lg < 20 else 5
+        t0 = time.perf_counter()
+        f.timer_start()
+        for _ in range(steps):
+            f.train_step(xd, opt, want_nll=False)
+        ms = f.timer_stop() / steps
+        f.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        print(json.dumps({"config": f"train step (fwd + bwd + Adam) variant C (RQS K=12) L=8 batch=2^{lg}",
+                          "ms_stream": ms, "ms_wall": wall, "samples_per_s": rows / ms * 1e3}), flush=True)
+
