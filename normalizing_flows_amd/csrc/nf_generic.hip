@@ -127,18 +127,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
 
 // ------------------------------------------------------------------------
 // Same product for the aligned case (lda, N, K multiples of 4, 16-byte aligned bases):
-// 128x128 block tile, BK = 32, float4 global loads, LDS double buffer with the next tile held
-// in registers while the current one computes (one barrier per k-tile), 2x2 waves of 64x64.
+// 128x128 block tile, BK = 32, float4 global loads, one 33 KB LDS stage with the next tile held in
+// registers while the current one computes, 2x2 waves of 64x64, FOUR workgroups per CU: with the
+// f32 MFMA blocking the vector issue a wave cannot overlap its own stash with its MFMAs, so the
+// overlap has to come from other workgroups (double-buffered at two per CU: 73 % MFMA-busy).
 // Blocks are renumbered so that each XCD's L2 sees a contiguous run of tiles.
 // ------------------------------------------------------------------------
 constexpr int FBM = 128, FBN = 128, FBK = 32;
-constexpr int kFastLdsFloats = 2 * (FBM * (FBK + 1) + FBK * FBN);
+constexpr int kFastLdsFloats = FBM * (FBK + 1) + FBK * FBN;  // one 33 KB stage: four workgroups per CU
 
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
+__global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kAs = FBM * (FBK + 1), kWs = FBK * FBN;  // buffer b: A at b*kAs, W at 2*kAs + b*kWs
+  constexpr int kAs = FBM * (FBK + 1);  // A tile, then the W tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -164,12 +166,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto stash = [&](int b) {
+  auto stash = [&]() {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float* a = smem + b * kAs + (ar + 32 * e) * (FBK + 1) + akq;
+      float* a = smem + (ar + 32 * e) * (FBK + 1) + akq;
       a[0] = ra[e].x; a[1] = ra[e].y; a[2] = ra[e].z; a[3] = ra[e].w;
-      *reinterpret_cast<float4*>(smem + 2 * kAs + b * kWs + (wk + 8 * e) * FBN + wc) = rw[e];
+      *reinterpret_cast<float4*>(smem + kAs + (wk + 8 * e) * FBN + wc) = rw[e];
     }
   };
 
@@ -183,13 +185,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
 
   const int nk = (K + FBK - 1) / FBK;
   fetch(0);
-  stash(0);
+  stash();
   __syncthreads();
+  const float* as = smem + (wm * 64 + i) * (FBK + 1) + h;
+  const float* ws = smem + kAs + h * FBN + wn * 64 + i;
   for (int kt = 0; kt < nk; ++kt) {
-    const int b = kt & 1;
     if (kt + 1 < nk) fetch((kt + 1) * FBK);
-    const float* as = smem + b * kAs + (wm * 64 + i) * (FBK + 1) + h;
-    const float* ws = smem + 2 * kAs + b * kWs + h * FBN + wn * 64 + i;
 #pragma unroll
     for (int s = 0; s < FBK / 2; ++s) {
       const float a0 = as[2 * s], a1 = as[32 * (FBK + 1) + 2 * s];
@@ -199,8 +200,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (kt + 1 < nk) stash(b ^ 1);
-    __syncthreads();
+    __syncthreads();  // every wave is done with this tile
+    if (kt + 1 < nk) {
+      stash();
+      __syncthreads();
+    }
   }
 
 #pragma unroll
