@@ -129,7 +129,7 @@ if "trainc" in which:   # `update` of src/maf_toy_densities.py:167-176 (spline f
                           rqs_range_min=-8.0, rqs_range_max=8.0)
     f = flow.CouplingFlow(cfg, spec.layers)
     opt = training.adam(1e-4)
-    for lg in (7, 12, 17, 20):
+    for lg in [int(v) for v in os.environ.get("NF_TRAINC_LG", "7,12,17,20").split(",")]:
         rows = 1 << lg
         xd = flow.DeviceArray.from_numpy(O.make_inputs("gaussian_blobs", rows))
         for _ in range(3):

@@ -290,3 +290,37 @@ def test_x3_env_default_covers_the_other_kernels(nfa, monkeypatch):
     assert s.get_option("hidden_matmul") == "f32"   # no MFMA in that kernel: the default does not apply
     monkeypatch.delenv("NF_HIDDEN_MATMUL")
     assert affine_flow(nfa, O.make_affine_spec(2, final_std=0.02)).get_option("hidden_matmul") == "f32"
+
+
+def test_x3_spline_flow_follows_training(nfa):
+    """The mode on a fused spline handle while it trains (general backward, float32): the split
+    image is rebuilt from the trained weights, like the float32 one."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(3, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    x = O.make_inputs("gaussian_blobs", 2048, seed=3)
+    for _ in range(3):
+        f.train_step(x, training.adam(1e-3), want_nll=False)
+    new_spec = O.make_rqs_spec(3, final_std=0.05)
+    new_spec.layers = f.get_weights()
+    assert np.abs(np.asarray(new_spec.layers[0][0][0]) - np.asarray(spec.layers[0][0][0])).max() > 1e-4
+    ref = O.log_prob(new_spec, x)
+    e32 = np.abs(O.log_prob(new_spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, "bf16x3 spline log_prob after training", 6 * e32)
+    f.set_option("hidden_matmul", "f32")
+    assert_close(f.log_prob(x), ref, "f32 spline log_prob after training", 4 * e32)
+
+
+def test_x3_general_path_training_keeps_the_split_weights_current(nfa):
+    from normalizing_flows_amd import training
+    spec = O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.05)
+    f = affine_flow(nfa, spec)
+    f.set_option("hidden_matmul", "bf16x3")
+    x = np.random.default_rng(2).standard_normal((1000, 8)).astype(np.float32)
+    for _ in range(2):
+        f.train_step(x, training.sgd(1e-2), want_nll=False)
+    new_spec = O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.05)
+    new_spec.layers = f.get_weights()
+    assert f.get_option("hidden_matmul") == "bf16x3"
+    assert_close(f.log_prob(x), O.log_prob(new_spec, x), "general bf16x3 log_prob after training")

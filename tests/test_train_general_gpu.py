@@ -157,3 +157,18 @@ def test_split_kind_on_the_general_path_still_refuses(nfa):
     f = nfa.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
     with pytest.raises(NFError):
         f.nll_grad(np.zeros((8, 4), np.float32))
+
+
+def test_gradient_all_reduce_single_rank(nfa):
+    """With a communicator attached the gradient goes through the RCCL all-reduce (one rank: identity)."""
+    from normalizing_flows_amd import sharding
+    spec = O.make_rqs_spec(2, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    x = O.make_inputs("gaussian_blobs", 1000, seed=4)
+    _, g0 = f.nll_grad(x)
+    comm = sharding.RcclComm(1, 0, sharding.RcclComm.new_unique_id())
+    f.attach_comm(comm)
+    _, g1 = f.nll_grad(x)
+    f.attach_comm(None)
+    comm.close()
+    assert np.array_equal(_flat(g0), _flat(g1))
