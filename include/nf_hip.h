@@ -218,13 +218,17 @@ int nf_nll(nf_flow* flow, const float* x, int64_t rows_local, int64_t rows_globa
 
 /* Same work, enqueue only (device pointers only): the scalar is written to
    slot `slot` (0..NF_NLL_SLOTS-1) of a pinned host ring the handle owns; read it
-   with nf_nll_result after nf_flow_synchronize. */
+   with nf_nll_result after nf_flow_synchronize.  With a communicator attached the
+   slots' local sums wait on the device and ONE all-reduce serves all waiting slots
+   when nf_flow_synchronize / nf_nll_result next run -- those two calls are then
+   collective: every rank must make them at the same points of its program. */
 #define NF_NLL_SLOTS 64
 int nf_nll_enqueue(nf_flow* flow, const float* x_dev, int64_t rows_local, int64_t rows_global,
                    float* out_log_prob_dev, int slot);
 int nf_nll_result(nf_flow* flow, int slot, double* out_nll);
 
-/* ---- training step (masked affine flows with the fused kernel) --------- */
+/* ---- training step (every masked coupling flow, and the split flow of
+   src/real_nvp.py) ------------------------------------------------------------------------- */
 typedef enum nf_optimizer_kind { NF_OPT_SGD = 0, NF_OPT_ADAM = 1 } nf_optimizer_kind;
 typedef struct nf_optimizer {
   int32_t kind;          /* nf_optimizer_kind */

@@ -79,9 +79,9 @@ struct nf_comm {
 
 namespace nf {
 
-int comm_allreduce_sum_f64(nf_comm* c, double* dev_value, hipStream_t stream) {
+int comm_allreduce_sum_f64(nf_comm* c, double* dev_values, size_t count, hipStream_t stream) {
   if (!c || !c->comm) { set_error("communicator is not initialised"); return NF_ERR_COMM; }
-  const int rc = g_rccl.all_reduce(dev_value, dev_value, 1, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, stream);
+  const int rc = g_rccl.all_reduce(dev_values, dev_values, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, stream);
   if (rc != 0) return rccl_fail(rc, "ncclAllReduce");
   return NF_OK;
 }

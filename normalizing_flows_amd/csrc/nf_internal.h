@@ -243,7 +243,7 @@ int launch_debug_read_f2(const float* x, long long rows, float* out, hipStream_t
 int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream);
 
 // ---- RCCL (dlopen'ed) ---------------------------------------------------------
-int comm_allreduce_sum_f64(nf_comm* comm, double* dev_value, hipStream_t stream);
+int comm_allreduce_sum_f64(nf_comm* comm, double* dev_values, size_t count, hipStream_t stream);
 int comm_allreduce_sum_f32(nf_comm* comm, float* dev_values, size_t count, hipStream_t stream);
 
 }  // namespace nf
