@@ -30,12 +30,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // W row-major [K,N], C row-major with leading dim ldc.
 // MFMA 32x32x2 f32: rows = samples, cols = output units.
 // ------------------------------------------------------------------------
-constexpr int BK = 16;
+// BK (template): depth of one LDS stage: 16 in general; 64 when K <= 64, so that the narrow layers of the
+// 2-D flows (and their backward products) need one stage and two barriers instead of four dependent rounds
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int act) {
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, const float* __restrict__ aux) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -91,8 +92,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
     }
     __syncthreads();
     if (k0 + BK < K) fetch(k0 + BK);
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
+    const int steps = ((K - k0 < BK ? K - k0 : BK) + 1) / 2;  // a short K (first Linear of a 2-D flow: 2) stops early
+#pragma unroll 4
+    for (int s = 0; s < steps; ++s) {
       float a[TM], b[TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) a[t] = As[wm * (TM * 32) + t * 32 + i][2 * s + h];
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
         float v = acc[t][u][r] + bv;
         if (act == 1) v = fmaxf(v, 0.f);
         else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+        else if (act >= 3) v = aux[(size_t)row * ldc + col] > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
         Cm[(size_t)row * ldc + col] = v;
       }
     }
@@ -138,7 +141,7 @@ constexpr int kFastLdsFloats = FBM * (FBK + 1) + FBK * FBN;  // one 33 KB stage:
 
 __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy) {
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy, const float* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kAs = FBM * (FBK + 1);  // A tile, then the W tile
 
@@ -221,13 +224,16 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
         float v = acc[t][u][r] + bv;
         if (act == 1) v = fmaxf(v, 0.f);
         else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+        else if (act >= 3) v = aux[(size_t)row * ldc + col] > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
         Cm[(size_t)row * ldc + col] = v;
       }
     }
 }
 
+// act: 0 none, 1 relu, 2 leaky_relu; 3 / 4: the backward forms -- the result is multiplied by
+// relu' / leaky_relu' of `aux` (an activation OUTPUT of the same shape and leading dimension as C)
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
-                       int M, int N, int K, int act, hipStream_t stream) {
+                       int M, int N, int K, int act, hipStream_t stream, const float* aux) {
   const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
   if (aligned && N >= 128 && K >= 32 && getenv("NF_GEMM_SIMPLE") == nullptr) {
@@ -239,18 +245,22 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
     }
     const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
     hipLaunchKernelGGL(gemm_fast_kernel, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
-                       W, bias, Cm, ldc, M, N, K, act, gx, gy);
+                       W, bias, Cm, ldc, M, N, K, act, gx, gy, aux);
     NF_HIP(hipGetLastError());
     return NF_OK;
   }
   if (N > 64) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_bias_act_kernel<128, 128, 2, 2>), grid, dim3(256), 0, stream, A, lda, W,
-                       bias, Cm, ldc, M, N, K, act);
+    hipLaunchKernelGGL((gemm_bias_act_kernel<128, 128, 2, 2, 16>), grid, dim3(256), 0, stream, A, lda, W,
+                       bias, Cm, ldc, M, N, K, act, aux);
   } else {
     dim3 grid((N + 63) / 64, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_bias_act_kernel<128, 64, 4, 1>), grid, dim3(256), 0, stream, A, lda, W,
-                       bias, Cm, ldc, M, N, K, act);
+    if (K <= 64 && M <= 8192)  // latency-bound sizes: one stage; at large M the smaller stage keeps more blocks per CU
+      hipLaunchKernelGGL((gemm_bias_act_kernel<128, 64, 4, 1, 64>), grid, dim3(256), 0, stream, A, lda, W,
+                         bias, Cm, ldc, M, N, K, act, aux);
+    else
+      hipLaunchKernelGGL((gemm_bias_act_kernel<128, 64, 4, 1, 16>), grid, dim3(256), 0, stream, A, lda, W,
+                         bias, Cm, ldc, M, N, K, act, aux);
   }
   NF_HIP(hipGetLastError());
   return NF_OK;
@@ -836,7 +846,7 @@ int Plan::set_x3(bool on) {
 void Plan::release() {
   if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
-  hipFree(bwd.d_scratch); hipFree(bwd.d_tape);
+  hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
   bwd = Backward();
   if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }
   host_weights.clear();
@@ -929,6 +939,8 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
+        if (record_tape)  // training: every Linear's output stays (hidden activations and theta)
+          dst = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * L.N;
         if (x3 && d_wx3 && gemm_x3_applicable(a, lda, L.N, L.K))
           NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
                                 j == nlin - 1 ? 0 : act, stream));
@@ -938,7 +950,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         a = dst;
         lda = L.N;
       }
-      NF_TRY(launch_transform(d, yc, ldc, buf[2], n, par, io.inverse_op, rc, stream));
+      NF_TRY(launch_transform(d, yc, ldc, a /* the last Linear's output */, n, par, io.inverse_op, rc, stream));
       NF_HIP(hipGetLastError());
     }
   }

@@ -3,16 +3,20 @@
 // computes in src/real_nvp_toy_densities.py:164-173, src/maf_toy_densities.py:167-176 and
 // src/maf_mnist.py:159-168.  SURVEY.md 8f rank 2 ("backward of K1 / K4").
 //
-// The forward walk keeps every layer's INPUT (rows x D floats per layer: 64 MB for the 2-D flows at
-// batch 2^20, 1.2 GB for the MNIST shape at 2^16 -- small change against 288 GB of HBM); hidden
-// activations and conditioner outputs are NOT kept.  Going back through the chain, every layer
-//   1. re-runs the conditioner on its recorded input                       -> a_1 .. a_n, theta
-//   2. (nothing to invert: unlike the affine map, a spline's float32 inverse can be off by
-//      1e-4 where |dx/dy| is large, and the parameter gradients inherit that error -- measured)
+// The forward walk keeps every layer's input, hidden activations and conditioner output (2-D
+// flows at batch 2^20: 5.6 GB; the MNIST shape at 2^16: 19 GB -- memory is what a 288 GB part has
+// to spend; up to 64 GiB, beyond that the batch must be split by the caller).  Going back through
+// the chain, every layer
+//   1. finds a_1 .. a_n and theta on the tape (the first build recomputed them: three more GEMMs
+//      per layer)
+//   2. has nothing to invert: unlike the affine map, a spline's float32 inverse can be off by
+//      1e-4 where |dx/dy| is large, and the parameter gradients inherit that error (measured when
+//      the first build re-derived the inputs from the output)
 //   3. transform backward: d theta and dL/dx of the transformed dims from dL/dy and dL/d(logdet)
 //   4. MLP backward: [dW_j; db_j] += [a_{j-1}, 1]^T g (rows on the MFMA k dimension, fixed-order
-//      partial sums), g <- (g W_j^T) * act'(a_{j-1}) (the forward GEMM kernels on a
-//      transposed copy of W_j), and finally dL/dx of the pass-through dims += g W_1^T.
+//      partial sums), g <- (g W_j^T) * act'(a_{j-1}) (the forward GEMM kernels on a transposed
+//      copy of W_j, the activation mask in their epilogue), and finally dL/dx of the pass-through
+//      dims += g W_1^T.
 // Gradients are accumulated in the plan's own weight layout (masked rows / pruned columns are
 // structural zeros there) and scattered to the canonical layout at the end.
 //
@@ -38,26 +42,26 @@ __global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict_
     g[q] = base == NF_BASE_STD_NORMAL ? z[q] * inv_n : 0.f;  // -d/dz log N(z; 0, 1) = z
 }
 
-__global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ g, const float* __restrict__ a,
-                                                       long long total, int act) {
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-    const float v = a[q];  // post-activation value: its sign is the pre-activation's
-    g[q] = v > 0.f ? g[q] : (act == 2 ? 0.01f * g[q] : 0.f);
-  }
-}
-
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                   long long total) {
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
     dst[q] += src[q];
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int K,
-                                                        int N) {
-  const long long total = (long long)K * N;
+// every Linear's W [K][N] -> WT [N][K] in one launch: blockIdx.y picks the Linear from a device table
+struct TransposeJob {
+  unsigned long long w_off, wT_off;
+  int K, N;
+};
+__global__ __launch_bounds__(256) void transpose_all_kernel(const float* __restrict__ weights, float* __restrict__ wT,
+                                                            const TransposeJob* __restrict__ jobs) {
+  const TransposeJob job = jobs[blockIdx.y];
+  const long long total = (long long)job.K * job.N;
+  const float* W = weights + job.w_off;
+  float* WT = wT + job.wT_off;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-    const int n = (int)(q / K), k = (int)(q % K);
-    WT[q] = W[(size_t)k * N + n];
+    const int n = (int)(q / job.K), k = (int)(q % job.K);
+    WT[q] = W[(size_t)k * job.N + n];
   }
 }
 
@@ -417,11 +421,17 @@ int Plan::prepare_backward() {
   // up to 256 row-chunk slabs of the largest Linear, at most 512 MiB
   b.partial_floats = std::max(biggest, std::min<size_t>(biggest * 256, ((size_t)512 << 20) / sizeof(float)));
   NF_HIP(hipMalloc(&b.d_partials, b.partial_floats * sizeof(float)));
-  for (size_t q = 0; q < linears.size(); ++q) {
-    const Linear& L = linears[q];
-    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)L.K * L.N, 2048)), dim3(256), 0, 0,
-                       d_weights + L.w_off, b.d_wT + b.wT_off[q], L.K, L.N);
-  }
+  std::vector<TransposeJob> jobs(linears.size());
+  for (size_t q = 0; q < linears.size(); ++q)
+    jobs[q] = TransposeJob{(unsigned long long)linears[q].w_off, (unsigned long long)b.wT_off[q], linears[q].K,
+                           linears[q].N};
+  hipFree(b.d_jobs);
+  b.d_jobs = nullptr;
+  NF_HIP(hipMalloc(&b.d_jobs, jobs.size() * sizeof(TransposeJob)));
+  NF_HIP(hipMemcpy(b.d_jobs, jobs.data(), jobs.size() * sizeof(TransposeJob), hipMemcpyHostToDevice));
+  b.transpose_blocks = grid_for((long long)biggest, 256);
+  hipLaunchKernelGGL(transpose_all_kernel, dim3(b.transpose_blocks, (unsigned)linears.size()), dim3(256), 0, 0,
+                     d_weights, b.d_wT, static_cast<const TransposeJob*>(b.d_jobs));
   NF_HIP(hipGetLastError());
   NF_HIP(hipDeviceSynchronize());
   b.ready = true;
@@ -432,11 +442,8 @@ int Plan::refresh_from_canonical(const float* d_canon, hipStream_t stream) {
   Backward& b = bwd;
   hipLaunchKernelGGL(gather_weights_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream,
                      d_canon, b.d_canon_index, d_weights, (long long)b.n_weights);
-  for (size_t q = 0; q < linears.size(); ++q) {
-    const Linear& L = linears[q];
-    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)L.K * L.N, 2048)), dim3(256), 0, stream,
-                       d_weights + L.w_off, b.d_wT + b.wT_off[q], L.K, L.N);
-  }
+  hipLaunchKernelGGL(transpose_all_kernel, dim3(b.transpose_blocks, (unsigned)linears.size()), dim3(256), 0, stream,
+                     d_weights, b.d_wT, static_cast<const TransposeJob*>(b.d_jobs));
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
@@ -449,10 +456,26 @@ int Plan::ensure_tape(long long rows) {
     set_error("training batch needs %zu bytes of layer inputs, more than the 64 GiB this build allows", bytes);
     return NF_ERR_UNSUPPORTED;
   }
+  size_t widths = 0;
+  for (const Linear& L : linears) widths += (size_t)L.N;
+  const size_t act_bytes = sizeof(float) * widths * (size_t)rows;
+  if (bytes + act_bytes > ((size_t)64 << 30)) {
+    set_error("training batch needs %zu bytes of recorded activations, more than the 64 GiB this build allows: "
+              "split the batch", bytes + act_bytes);
+    return NF_ERR_UNSUPPORTED;
+  }
   hipFree(b.d_tape);
-  b.d_tape = nullptr;
+  hipFree(b.d_acts);
+  b.d_tape = b.d_acts = nullptr;
   b.tape_rows = 0;
   NF_HIP(hipMalloc(&b.d_tape, bytes));
+  NF_HIP(hipMalloc(&b.d_acts, act_bytes));
+  b.act_off.clear();
+  size_t off = 0;
+  for (const Linear& L : linears) {
+    b.act_off.push_back(off);
+    off += (size_t)L.N * rows;
+  }
   b.tape_rows = rows;
   return NF_OK;
 }
@@ -467,9 +490,9 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
   const int act = d.activation == NF_ACT_RELU ? 1 : 2;
   const RqsConst rc = make_rqs_const(d);
   const float inv_n = 1.f / (float)rows_global, gld = -inv_n;
-  // scratch per row: hidden activations, theta, d theta, two gradient buffers, one log-det column
+  // scratch per row: d theta and two gradient buffers
   const int gwidth = std::max(act_width, D);
-  const size_t per_row = ((size_t)nh * act_width + 2 * (size_t)param_width + 2 * (size_t)gwidth) * sizeof(float);
+  const size_t per_row = ((size_t)param_width + 2 * (size_t)gwidth) * sizeof(float);
   long long cap = (long long)(((size_t)4 << 30) / per_row);
   cap = std::max<long long>(128, cap / 128 * 128);
   const long long want = std::min(rows, cap);
@@ -485,9 +508,7 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
   hipLaunchKernelGGL(base_grad_kernel, dim3(grid_for(rows * D)), dim3(256), 0, stream, v, g, rows * D, d.base, inv_n);
 
   const long long R = b.scratch_rows;
-  float* acts = b.d_scratch;                                   // [nh][R][act_width]
-  float* th = acts + (size_t)nh * R * act_width;               // [R][param_width]
-  float* dth = th + (size_t)R * param_width;
+  float* dth = b.d_scratch;                                    // [R][param_width]
   float* ga = dth + (size_t)R * param_width;                   // [R][gwidth]
   float* gb = ga + (size_t)R * gwidth;
   for (long long r0 = 0; r0 < rows; r0 += R) {
@@ -497,16 +518,9 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       const int par = (d.first_mask_parity + l) & 1;
       const Linear* Ls = &linears[(size_t)l * nlin];
       const float* vc = b.d_tape + ((size_t)l * b.tape_rows + r0) * D;  // this layer's input
-      // 1. conditioner on the recorded input
-      const float* a = vc;
-      int lda = D;
-      for (int j = 0; j < nlin; ++j) {
-        float* dst = j == nlin - 1 ? th : acts + (size_t)j * R * act_width;
-        NF_TRY(launch_gemm(a, lda, d_weights + Ls[j].w_off, d_weights + Ls[j].b_off, dst, Ls[j].N, (int)n, Ls[j].N,
-                           Ls[j].K, j == nlin - 1 ? 0 : act, stream));
-        a = dst;
-        lda = Ls[j].N;
-      }
+      // the recorded outputs of this layer's Linears: hidden activations, then theta
+      auto recorded = [&](int j) { return b.d_acts + b.act_off[(size_t)l * nlin + j] + (size_t)r0 * Ls[j].N; };
+      const float* th = recorded(nlin - 1);
       // 3. transform backward
       if (d.kind == NF_KIND_AFFINE_MASKED) {
         hipLaunchKernelGGL(affine_masked_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, vc, gc, th, dth, n, D,
@@ -524,16 +538,15 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       const float* gcur = dth;
       for (int j = nlin - 1; j >= 0; --j) {
         const Linear& L = Ls[j];
-        const float* ain = j == 0 ? vc : acts + (size_t)(j - 1) * R * act_width;
+        const float* ain = j == 0 ? vc : recorded(j - 1);
         const int lain = j == 0 ? D : Ls[j - 1].N;
         NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
                              b.partial_floats, stream));
         float* gprev = (gcur == ga) ? gb : ga;
+        // j > 0: times act'(a_{j-1}) in the GEMM's epilogue (codes 3 / 4, masked by the sign of `ain`)
         NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gprev, L.K, (int)n, L.K,
-                           L.N, 0, stream));
-        if (j > 0) {
-          hipLaunchKernelGGL(act_grad_kernel, dim3(grid_for(n * L.K)), dim3(256), 0, stream, gprev, ain, n * L.K, act);
-        } else {
+                           L.N, j > 0 ? act + 2 : 0, stream, j > 0 ? ain : nullptr));
+        if (j == 0) {
           // rows of W_1 that belong to transformed dims are structural zeros: nothing flows there
           hipLaunchKernelGGL(add_kernel, dim3(grid_for(n * D)), dim3(256), 0, stream, gc, gprev, n * D);
         }

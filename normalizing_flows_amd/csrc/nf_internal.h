@@ -179,7 +179,7 @@ struct RqsConst {
 };
 RqsConst make_rqs_const(const nf_flow_desc& d);
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K,
-                int act, hipStream_t stream);
+                int act, hipStream_t stream, const float* aux = nullptr);
 int launch_transform(const nf_flow_desc& d, float* y, float* ld, const float* params, long long n, int par,
                      int inverse_op, const RqsConst& rc, hipStream_t stream);
 
@@ -205,6 +205,8 @@ struct Plan {
     float* d_wT = nullptr;           // every Linear's W transposed, [N][K], at wT_off
     std::vector<size_t> wT_off;
     int* d_canon_index = nullptr;
+    void* d_jobs = nullptr;          // per-Linear table of the one-launch transpose
+    int transpose_blocks = 1;
     float* d_zero = nullptr;         // zero bias for the data-gradient GEMMs
     float* d_partials = nullptr;     // weight-gradient partial sums, one slab per row chunk
     size_t partial_floats = 0;
@@ -212,6 +214,8 @@ struct Plan {
     long long scratch_rows = 0;
     float* d_tape = nullptr;         // [num_layers][tape_rows][D]: every layer's input from the forward walk
     long long tape_rows = 0;
+    float* d_acts = nullptr;         // every Linear's output of that walk: [tape_rows][N] at act_off[layer*nlin+j]
+    std::vector<size_t> act_off;
   } bwd;
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
