@@ -372,8 +372,11 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, const RqsC
     if (v <= c.range_min) { res = (v - c.range_min) / s_first + c.range_min; ldv = -logf(s_first); }
     if (v >= c.range_max) { res = (v - c.range_max) / s_last + c.range_max; ldv = -logf(s_last); }
   }
-  *out = res;
-  *logdet = ldv;
+  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
+  // kernels are built with -fno-honor-nans)
+  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
+  *out = v_nan ? v : res;
+  *logdet = v_nan ? v : ldv;
 }
 
 // G lanes (power of two <= 64) share one row: each takes transformed dims dt = sub, sub+G, ...
@@ -482,8 +485,11 @@ __device__ __forceinline__ void rqs_eval_reg(const float* __restrict__ p, const 
     res = INV ? (v - edge) * __builtin_amdgcn_rcpf(s) + edge : (v - edge) * s + edge;
     ldv = INV ? -flog(s) : flog(s);
   }
-  *out = res;
-  *logdet = ldv;
+  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
+  // kernels are built with -fno-honor-nans)
+  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
+  *out = v_nan ? v : res;
+  *logdet = v_nan ? v : ldv;
 }
 
 template <int K, int INV>

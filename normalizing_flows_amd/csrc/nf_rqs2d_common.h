@@ -145,8 +145,11 @@ __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K
       if (above) { res = fast_div(v - p.range_max, s_last) + p.range_max; ldv = -fast_log(s_last); }
     }
   }
-  *out = res;
-  *logdet = ldv;
+  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
+  // kernels are built with -fno-honor-nans)
+  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
+  *out = v_nan ? v : res;
+  *logdet = v_nan ? v : ldv;
 }
 
 }  // namespace rqs2d

@@ -654,3 +654,58 @@ def test_split_nll_gradient_and_sgd(nfa, L, H, rows):
     assert np.abs(_flat(f.get_weights()) - want).max() <= 1e-6
     new_params = [[[W, b] for W, b in layer] for layer in f.get_weights()]
     assert_close(f.log_prob(y), O.a_log_prob_chain(new_params, flips, y), "A log_prob after sgd step")
+
+
+# ------------------------------------------------------------------ non-finite and extreme inputs
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("kind", ["affine_fused", "rqs_fused", "affine_general", "rqs_general", "rqs_general_k4", "split"])
+def test_non_finite_inputs_stay_in_their_rows(nfa, kind, mode):
+    """jax propagates NaN through log_prob; a NaN / inf / 1e30 coordinate must make its own row's
+    result non-finite (or a huge negative log_prob) and leave every other row exactly as it was --
+    the relu in the kernels is a clamp / v_max compiled under -fno-honor-nans, which this pins."""
+    from normalizing_flows_amd._lib import NFError
+    rng = np.random.default_rng(7)
+    if kind == "affine_fused":
+        spec = O.make_affine_spec(4, final_std=0.02)
+        f, D = affine_flow(nfa, spec), 2
+    elif kind == "rqs_fused":
+        spec = O.make_rqs_spec(3, final_std=0.05)
+        f, D = rqs_flow(nfa, spec), 2
+    elif kind == "affine_general":
+        spec = O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03)
+        f, D = affine_flow(nfa, spec), 8
+    elif kind == "rqs_general":      # rqs_rows_kernel<8>
+        spec = O.make_rqs_spec(2, event_size=6, hidden=(64, 64), num_bins=8, range_min=-4.0, range_max=4.0,
+                               final_std=0.1)
+        f, D = rqs_flow(nfa, spec), 6
+    elif kind == "rqs_general_k4":   # rqs_masked_kernel
+        spec = O.make_rqs_spec(2, event_size=5, hidden=(32,), num_bins=4, range_min=-4.0, range_max=4.0,
+                               final_std=0.1)
+        f, D = rqs_flow(nfa, spec), 5
+    else:
+        f, D = split_flow(nfa, O.make_a_params(4)[0]), 2
+    try:
+        f.set_option("hidden_matmul", mode)
+    except NFError:
+        assert kind == "split" and mode == "bf16x3"
+        return
+    if kind.startswith("rqs_general") or kind == "affine_general":
+        assert f.kernel_name == "generic_gemm"
+    x = (rng.standard_normal((300, D)) * 1.5).astype(np.float32)
+    clean = f.log_prob(x)
+    assert np.isfinite(clean).all()
+    bad = x.copy()
+    bad[3, 0] = np.nan
+    bad[40, D - 1] = np.inf
+    bad[41, 0] = -np.inf
+    bad[100, 0] = 1e30
+    bad[200, D - 1] = -3e38
+    got = f.log_prob(bad)
+    touched = np.zeros(300, bool)
+    touched[[3, 40, 41, 100, 200]] = True
+    assert np.array_equal(got[~touched], clean[~touched])
+    assert np.isnan(got[3])
+    for r in (40, 41, 100, 200):
+        assert not np.isfinite(got[r]) or got[r] < -1e20, (r, got[r])
+    nll = f.nll(bad)
+    assert not np.isfinite(nll) or nll > 1e15
