@@ -709,3 +709,20 @@ def test_non_finite_inputs_stay_in_their_rows(nfa, kind, mode):
         assert not np.isfinite(got[r]) or got[r] < -1e20, (r, got[r])
     nll = f.nll(bad)
     assert not np.isfinite(nll) or nll > 1e15
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_empty_batches_on_every_path(nfa, mode):
+    from normalizing_flows_amd import _lib
+    flows = [(affine_flow(nfa, O.make_affine_spec(3, final_std=0.02)), 2),
+             (rqs_flow(nfa, O.make_rqs_spec(2, final_std=0.05)), 2),
+             (affine_flow(nfa, O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03)), 8),
+             (rqs_flow(nfa, O.make_rqs_spec(2, event_size=6, hidden=(64, 64), num_bins=8, final_std=0.1)), 6)]
+    for f, D in flows:
+        f.set_option("hidden_matmul", mode)
+        empty = np.zeros((0, D), np.float32)
+        assert f.log_prob(empty).shape == (0,)
+        y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, empty)
+        assert y.shape == (0, D) and ld.shape == (0,)
+        one = np.full((1, D), 0.25, np.float32)        # and the smallest non-empty batch right after
+        assert np.isfinite(f.log_prob(one)).all()
