@@ -15,9 +15,11 @@ from .conditioner import (MLPConditioner, layers_from_haiku_params, layers_to_ha
 from .distributions import (Distribution, Independent, MultivariateNormalDiag, Normal, Transformed,
                             Uniform)
 from .flow import CouplingFlow, DeviceArray, FlowConfig
+from .mnist import prepare_data
 from .sharding import RcclComm, ShardedNLL, shard_rows
 
 __all__ = [
+    "prepare_data",
     "NFError", "Bijector", "Chain", "Inverse", "MaskedCoupling", "RationalQuadraticSpline", "ScalarAffine",
     "MLPConditioner", "layers_from_haiku_params", "layers_to_haiku_params", "load_params", "save_params",
     "make_conditioner", "Distribution", "Independent",

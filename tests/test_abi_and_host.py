@@ -241,3 +241,19 @@ def test_sharded_nll_gloo_world2():
     spec = O.make_affine_spec(4, final_std=0.02)
     x = O.make_inputs("banana", 4097)
     assert abs(vals[0] - O.nll(spec, x)) < 1e-12
+
+
+def test_prepare_data_matches_the_reference_arithmetic():
+    """src/maf_mnist.py:101-106: float32(image) / 256, noise in [0, 1) only with a key."""
+    from normalizing_flows_amd import prepare_data
+    img = np.arange(2 * 28 * 28, dtype=np.uint32).reshape(2, 28, 28, 1).astype(np.uint8)
+    out = prepare_data({"image": img})
+    assert out.dtype == np.float32 and out.shape == img.shape
+    assert np.array_equal(out, img.astype(np.float32) / 256.0)
+    assert out.min() >= 0.0 and out.max() < 1.0
+    noisy = prepare_data({"image": img}, prng_key=42)
+    d = noisy * 256.0 - img
+    assert (d >= 0).all() and (d < 1.0 + 1e-6).all() and d.std() > 0.2
+    assert np.array_equal(noisy, prepare_data(img, prng_key=42))          # reproducible, accepts the array itself
+    assert not np.array_equal(noisy, prepare_data(img, prng_key=43))
+
