@@ -16,6 +16,7 @@
 // The default remains the exact-f32 kernel (nf_affine2d_h64.hip); everything else -- first
 // Linear in operand layout (clamp-bit relu), last Linear on the accumulator, streaming of layer
 // images through an LDS double buffer -- is as in nf_affine2d_h64.hip / nf_rqs2d_h64.hip.
+#include "nf_bf16x3.h"
 #include "nf_internal.h"
 
 #include <math.h>
@@ -26,24 +27,10 @@
 namespace nf {
 namespace affine2d_x3 {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using bf16x3::bf16x8;
+using bf16x3::f32x16;
+using bf16x3::split3;
 constexpr int kReluShift = 64;
-
-// ---- host: round-to-nearest-even bf16 split ------------------------------------------------
-static unsigned short bf16_rne(float x) {
-  unsigned u;
-  memcpy(&u, &x, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-static float bf16_to_float(unsigned short b) {
-  unsigned u = (unsigned)b << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
 
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                 const float* b3, int cond_dim, float* img) {
@@ -54,12 +41,8 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
           const int k = 16 * s + 8 * (lane >> 5) + j, u = 32 * m + (lane & 31);
-          const float w = ldexpf(W2[k * 64 + u], kReluShift);
-          const unsigned short hi = bf16_rne(w);
-          const float r1 = w - bf16_to_float(hi);
-          const unsigned short mid = bf16_rne(r1);
-          const unsigned short lo = bf16_rne(r1 - bf16_to_float(mid));
-          const unsigned short part[3] = {hi, mid, lo};
+          unsigned short part[3];
+          bf16x3::host_split3(ldexpf(W2[k * 64 + u], kReluShift), part);
           for (int p = 0; p < 3; ++p) a[((((p * 4 + s) * 2 + m) * 64) + lane) * 8 + j] = part[p];
         }
   for (int k = 0; k < 64; ++k) {
@@ -103,34 +86,6 @@ __device__ __forceinline__ float exp_f32(float x) {
   const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
   const float e = __builtin_amdgcn_exp2f(hi);
   return fmaf(e, lo * kLn2, e);
-}
-
-// eight float32 values -> their (hi, mid, lo) bf16 parts, round-to-nearest at every level.
-// v == hi + mid + lo exactly (the residual after two 8-bit parts has at most 8 significant bits).
-// 11 VALU per pair: the compiler's own lowering of (__bf16) casts converts element by element.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 ph, pm, pl;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = v[2 * q], b = v[2 * q + 1];
-    const unsigned h = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    ph[q] = h;
-    pm[q] = m;
-    pl[q] = cvt_pk_bf16(sa, sb);
-  }
-  hi = __builtin_bit_cast(bf16x8, ph);
-  mid = __builtin_bit_cast(bf16x8, pm);
-  lo = __builtin_bit_cast(bf16x8, pl);
 }
 
 template <int T, int WAVES, int INV>
@@ -249,14 +204,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? WAVES / 4 : 2) void chain_
         if (q + 1 < 4 * T) make_B(q + 1);
         const bf16x8 Bh = B[q & 1][0], Bm = B[q & 1][1], Bl = B[q & 1][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {  // smallest terms first
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[m], Bh, acc[t][m], 0, 0, 0);
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[m], Bl, acc[t][m], 0, 0, 0);
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[m], Bm, acc[t][m], 0, 0, 0);
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[m], Bh, acc[t][m], 0, 0, 0);
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[m], Bm, acc[t][m], 0, 0, 0);
-          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[m], Bh, acc[t][m], 0, 0, 0);
-        }
+        for (int m = 0; m < 2; ++m) bf16x3::mfma6(acc[t][m], Ah[m], Am[m], Al[m], Bh, Bm, Bl);
         if (q + 1 < 4 * T) {
 #pragma unroll
           for (int g = 0; g < 12; ++g) {  // 52 VALU of the next split spread over these 12 MFMAs

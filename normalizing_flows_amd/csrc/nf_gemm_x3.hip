@@ -18,6 +18,7 @@
 //     with a 16-deep k step the row-major bf16 tile IS the A operand order.
 // 128x128 block tile, BK = 32, 4 waves of 64x64, one 48 KiB LDS stage + the next tile in
 // registers, three workgroups per CU (144 KiB of LDS, <= 168 registers).
+#include "nf_bf16x3.h"
 #include "nf_internal.h"
 
 #include <math.h>
@@ -26,29 +27,14 @@
 namespace nf {
 namespace generic {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+using bf16x3::bf16x8;
+using bf16x3::f32x16;
+using bf16x3::split_pair;
 
 constexpr int XBM = 128, XBN = 128, XBK = 32;
 constexpr int kTileU4 = 3 * 2 * 4 * 64;  // uint4 (8 bf16) per W tile image = 1536 (24 KiB)
 
 // ---- host ------------------------------------------------------------------------------------
-static unsigned short bf16_rne(float x) {
-  unsigned u;
-  memcpy(&u, &x, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-static float bf16_to_float(unsigned short b) {
-  unsigned u = (unsigned)b << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
 size_t x3_image_halfwords(int K, int N) {
   const size_t nb = (N + XBN - 1) / XBN, nkt = (K + XBK - 1) / XBK;
   return nb * nkt * (size_t)kTileU4 * 8;
@@ -67,30 +53,14 @@ void pack_w_x3(const float* W, int K, int N, unsigned short* img) {
               const int k = kt * XBK + ks * 16 + 8 * (lane >> 5) + j;
               const int n = b * XBN + nt * 32 + (lane & 31);
               if (k >= K || n >= N) continue;
-              const float w = W[(size_t)k * N + n];
-              const unsigned short hi = bf16_rne(w);
-              const float r1 = w - bf16_to_float(hi);
-              const unsigned short mid = bf16_rne(r1);
-              const unsigned short lo = bf16_rne(r1 - bf16_to_float(mid));
-              const unsigned short part[3] = {hi, mid, lo};
+              unsigned short part[3];
+              bf16x3::host_split3(W[(size_t)k * N + n], part);
               for (int p = 0; p < 3; ++p) tile[((((p * 2 + ks) * 4 + nt) * 64) + lane) * 8 + j] = part[p];
             }
     }
 }
 
 // ---- device ----------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-  mid = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
-  lo = cvt_pk_bf16(sa, sb);
-}
-
 __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int lda,
                                                          const uint4* __restrict__ Wimg,
                                                          const float* __restrict__ bias, float* __restrict__ Cm,
@@ -178,14 +148,8 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {  // smallest terms first
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][2], Bf[u][0], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][0], Bf[u][2], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][1], Bf[u][1], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][1], Bf[u][0], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][0], Bf[u][1], acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[t][0], Bf[u][0], acc[t][u], 0, 0, 0);
-        }
+        for (int u = 0; u < 2; ++u)
+          bf16x3::mfma6(acc[t][u], Af[t][0], Af[t][1], Af[t][2], Bf[u][0], Bf[u][1], Bf[u][2]);
     }
     __syncthreads();
     if (kt + 1 < nk) {

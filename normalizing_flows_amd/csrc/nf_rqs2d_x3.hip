@@ -14,6 +14,7 @@
 //   * with 32-cycle MFMAs the spline's ~600 VALU instructions are no longer serialised behind
 //     the matrix pipe (the f32 MFMA blocks the vector issue for its whole 64 cycles, the bf16
 //     one for 8 of 32): the kernel is bound by vector issue, not by the MFMA.
+#include "nf_bf16x3.h"
 #include "nf_rqs2d_common.h"
 
 #include <math.h>
@@ -30,34 +31,17 @@ using rqs2d::lds_f32x16;
 using rqs2d::param_of_slot;
 using rqs2d::spline;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+using bf16x3::bf16x8;
+using bf16x3::split3;
 constexpr int kReluShift = 64;
 
 // ---- host ------------------------------------------------------------------------------------
-static unsigned short bf16_rne(float x) {
-  unsigned u;
-  memcpy(&u, &x, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-static float bf16_to_float(unsigned short b) {
-  unsigned u = (unsigned)b << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
 static void split_store(float w, unsigned short* base, size_t part_stride, size_t at) {
-  const unsigned short hi = bf16_rne(w);
-  const float r1 = w - bf16_to_float(hi);
-  const unsigned short mid = bf16_rne(r1);
-  const unsigned short lo = bf16_rne(r1 - bf16_to_float(mid));
-  base[at] = hi;
-  base[part_stride + at] = mid;
-  base[2 * part_stride + at] = lo;
+  unsigned short part[3];
+  bf16x3::host_split3(w, part);
+  base[at] = part[0];
+  base[part_stride + at] = part[1];
+  base[2 * part_stride + at] = part[2];
 }
 
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
@@ -98,36 +82,9 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
 }
 
 // ---- device ----------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 ph, pm, pl;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = v[2 * q], b = v[2 * q + 1];
-    const unsigned h = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    ph[q] = h;
-    pm[q] = m;
-    pl[q] = cvt_pk_bf16(sa, sb);
-  }
-  hi = __builtin_bit_cast(bf16x8, ph);
-  mid = __builtin_bit_cast(bf16x8, pm);
-  lo = __builtin_bit_cast(bf16x8, pl);
-}
-
-// acc += A (3 parts) x B (3 parts), smallest terms first
+// acc += A (3 parts) x B (3 parts)
 __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&A)[3], const bf16x8 (&B)[3]) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], acc, 0, 0, 0);
+  bf16x3::mfma6(acc, A[0], A[1], A[2], B[0], B[1], B[2]);
 }
 
 template <int T, int WAVES, int INV, int K>
