@@ -45,6 +45,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "rqs_l8_blobs.npz"), weights=flat(spec.layers), x=x,
                         log_prob=O.log_prob(spec, x), z=z, logdet=ld, num_layers=8, num_bins=12,
                         range_min=-8.0, range_max=8.0)
+    # gradients of the NLL (the training step's known answers): headline flow, 4 layers, and a 3-layer spline flow
+    spec = O.make_affine_spec(4, final_std=0.03)
+    x = O.make_inputs("banana", 256, seed=2235)
+    nll, grads = O.affine_nll_and_grad(spec, x)
+    np.savez_compressed(os.path.join(HERE, "affine_l4_grad.npz"), weights=flat(spec.layers), x=x, nll=nll,
+                        grad=flat(grads), num_layers=4)
+    spec = O.make_rqs_spec(3, num_bins=8, range_min=-6.0, range_max=6.0, final_std=0.05)
+    x = O.make_inputs("gaussian_blobs", 256, seed=2235)
+    nll, grads = O.flow_nll_and_grad(spec, x)
+    np.savez_compressed(os.path.join(HERE, "rqs_l3_grad.npz"), weights=flat(spec.layers), x=x, nll=nll,
+                        grad=flat(grads), num_layers=3, num_bins=8, range_min=-6.0, range_max=6.0)
     # hand-computed case: 1 layer, H = (2, 2), numbers worked by hand below
     np.savez_compressed(os.path.join(HERE, "affine_hand_case.npz"), **hand_case())
 

@@ -235,6 +235,24 @@ def test_golden_split_and_rqs():
     assert np.array_equal(O.log_prob(spec, g["x"]), g["log_prob"])
 
 
+def test_golden_gradients():
+    """The training step's committed known answers (tests/golden/*_grad.npz)."""
+    g = np.load(os.path.join(GOLD, "affine_l4_grad.npz"))
+    spec = O.FlowSpec("affine", 2, unflat_affine(g["weights"], 4), O.alternating_masks(2, 4, 1))
+    nll, grads = O.affine_nll_and_grad(spec, g["x"])
+    flat = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for layer in grads for W, b in layer])
+    assert nll == float(g["nll"]) and np.array_equal(flat, g["grad"])
+    nll2, grads2 = O.flow_nll_and_grad(spec, g["x"])          # the general restatement agrees with the golden too
+    flat2 = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for layer in grads2 for W, b in layer])
+    assert abs(nll2 - nll) < 1e-12 and np.abs(flat2 - g["grad"]).max() < 1e-12
+    g = np.load(os.path.join(GOLD, "rqs_l3_grad.npz"))
+    spec = O.FlowSpec("rqs", 2, unflat_affine(g["weights"], 3, out=50), O.alternating_masks(2, 3, 1), "normal", 8,
+                      -6.0, 6.0)
+    nll, grads = O.flow_nll_and_grad(spec, g["x"])
+    flat = np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for layer in grads for W, b in layer])
+    assert nll == float(g["nll"]) and np.array_equal(flat, g["grad"])
+
+
 def test_synthetic_inputs_match_generator_statistics():
     """make_inputs restates src/densities/*.py: check the moments those generators imply."""
     b = O.make_inputs("banana", 200000).astype(np.float64)

@@ -172,3 +172,35 @@ def test_gradient_all_reduce_single_rank(nfa):
     f.attach_comm(None)
     comm.close()
     assert np.array_equal(_flat(g0), _flat(g1))
+
+
+def test_golden_gradients(nfa):
+    """HIP against the committed gradient vectors (tests/golden/*_grad.npz): the fused affine backward
+    and the general spline backward."""
+    import os
+    from normalizing_flows_amd import _lib
+    from test_oracle_kat import GOLD, unflat_affine
+    g = np.load(os.path.join(GOLD, "affine_l4_grad.npz"))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=4, hidden=(64, 64))
+    f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], 4))
+    nll, grads = f.nll_grad(g["x"])
+    assert abs(nll - float(g["nll"])) <= 1e-5
+    ref = unflat_affine(g["grad"], 4)
+    for l in range(4):
+        for j in range(3):
+            for which in (0, 1):
+                r = ref[l][j][which]
+                assert np.abs(grads[l][j][which] - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-6), (l, j, which)
+    g = np.load(os.path.join(GOLD, "rqs_l3_grad.npz"))
+    cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=3, hidden=(64, 64), rqs_bins=8,
+                         rqs_range_min=-6.0, rqs_range_max=6.0)
+    f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], 3, out=50))
+    nll, grads = f.nll_grad(g["x"])
+    assert abs(nll - float(g["nll"])) <= 1e-5 * max(1.0, abs(float(g["nll"])))
+    ref = unflat_affine(g["grad"], 3, out=50)
+    for l in range(3):
+        for j in range(3):
+            for which in (0, 1):
+                r = ref[l][j][which]
+                assert np.abs(grads[l][j][which] - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-6), (l, j, which)
+
