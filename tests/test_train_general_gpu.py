@@ -204,3 +204,44 @@ def test_golden_gradients(nfa):
                 r = ref[l][j][which]
                 assert np.abs(grads[l][j][which] - r).max() <= 2e-4 * max(np.abs(r).max(), 1e-6), (l, j, which)
 
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_shapes_forward_and_gradient(nfa, case):
+    """Seeded random masked flows on the general path: event size 2..11, one to three hidden layers of
+    width 8..96, affine or spline (K 2..14, random range), either mask parity, ragged row counts --
+    log_prob, both chain walks and the gradient against the oracle."""
+    from normalizing_flows_amd import _lib
+    rng = np.random.default_rng(1000 + case)
+    D = int(rng.integers(2, 12))
+    hidden = tuple(int(rng.integers(2, 25)) * 4 for _ in range(int(rng.integers(1, 4))))
+    L = int(rng.integers(1, 5))
+    parity = int(rng.integers(0, 2))
+    rows = int(rng.integers(1, 700))
+    if D == 2 and hidden == (64, 64):
+        hidden = (64, 60)   # keep it on the general path
+    if case % 2 == 0:
+        K = int(rng.integers(2, 15))
+        lo = -float(rng.uniform(2.0, 6.0))
+        hi = float(rng.uniform(2.0, 6.0))
+        spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=lo, range_max=hi,
+                               final_std=0.15, first_parity=parity, seed=case)
+        f = rqs_flow(nfa, spec, parity)
+    else:
+        spec = O.make_affine_spec(L, event_size=D, hidden=hidden, final_std=0.02, first_parity=parity, seed=case)
+        f = affine_flow(nfa, spec, parity)
+    assert f.kernel_name == "generic_gemm"
+    x = (rng.standard_normal((rows, D)) * 2.0).astype(np.float32)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, f"case {case} log_prob", 4 * e32)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    z32, ld32 = O.chain_forward(spec, x, np.float32)
+    assert_close(z, zr, f"case {case} z", 4 * np.abs(z32 - zr).max())
+    assert_close(ld, ldr, f"case {case} logdet", 4 * np.abs(ld32 - ldr).max())
+    xb, _ = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, _ = O.chain_inverse(spec, z)
+    x32, _ = O.chain_inverse(spec, z, np.float32)
+    assert_close(xb, xr, f"case {case} inverse", 4 * np.abs(x32 - xr).max())
+    check_grads(f, spec, x, tol=3e-4)
