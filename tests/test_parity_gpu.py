@@ -229,6 +229,29 @@ def test_affine_full_size_properties(nfa):
     assert_close(lp[idx], O.log_prob(spec, x[idx]), "strided oracle check")
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_affine_8m_rows_properties(nfa, mode):
+    """BASELINE.json configs[3]'s global batch on ONE GPU (2^23 rows, 8 passes of the persistent grid,
+    a row count that is not a multiple of anything: 2^23 - 5): properties, plus an oracle spot check."""
+    from normalizing_flows_amd import _lib
+    spec = O.make_affine_spec(8, final_std=0.02)
+    f = affine_flow(nfa, spec)
+    f.set_option("hidden_matmul", mode)
+    n = (1 << 23) - 5
+    x = O.make_inputs("banana", n, seed=77)
+    lp = f.log_prob(x)
+    assert np.isfinite(lp).all()
+    for s in (0, 4096 * 1001, n - 4099):
+        assert np.array_equal(f.log_prob(x[s:s + 4096]), lp[s:s + 4096])
+    idx = np.arange(0, n, 4099)
+    assert_close(lp[idx], O.log_prob(spec, x[idx]), "strided oracle check at 2^23 rows")
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    assert np.abs(xb - x).max() <= 1e-4 * max(1.0, np.abs(x).max())
+    assert np.abs(ld + ldb).max() <= 1e-4
+    assert abs(f.nll(x) + lp.astype(np.float64).mean()) <= 1e-9
+
+
 def test_errors(nfa):
     from normalizing_flows_amd import _lib
     spec = O.make_affine_spec(2)
