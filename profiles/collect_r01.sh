@@ -6,7 +6,7 @@ set -e
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_r01
 mkdir -p $OUT
-B="--no-cpu-baseline"
+B="--no-cpu-baseline --no-variants"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -- python3 bench.py --steps 50 --warmup 10 $B > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/fetch -- python3 bench.py --steps 5 --warmup 2 $B > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/write -- python3 bench.py --steps 5 --warmup 2 $B > $OUT/write.log 2>&1
