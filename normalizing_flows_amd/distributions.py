@@ -211,6 +211,12 @@ class Transformed(Distribution):
             raise ValueError(f"bijector event shape {event_shape} differs from the base's {self.event_shape}")
         return flow, direction
 
+    def set_option(self, name: str, value: str) -> None:
+        """nf_flow_set_option on the device flow behind this model, e.g. ("hidden_matmul", "bf16x3")
+        (nothing in distrax corresponds; the environment variable NF_HIDDEN_MATMUL sets the default)."""
+        flow, _ = self._lowered()
+        flow.set_option(name, value)
+
     def log_prob(self, value):
         """x, ildj = bijector.inverse_and_log_det(value); base.log_prob(x) + ildj -- one launch."""
         flow, direction = self._lowered()

@@ -351,3 +351,19 @@ def test_maf_mnist_training_step_shapes(distrax):
     for _ in range(5):
         training.update(model, training.adam(1e-4), x, want_loss=False)
     assert model.nll(x) < before
+
+
+def test_option_through_the_distrax_surface(distrax):
+    rng = np.random.default_rng(45)
+    model, layers = make_flow_model_affine(distrax, (2,), 4, [64, 64], rng, 0.02)
+    x = O.make_inputs("banana", 3000)
+    spec = spec_of(layers, "affine", 2)
+    ref = O.log_prob(spec, x)
+    lp32 = model.log_prob(x)
+    model.set_option("hidden_matmul", "bf16x3")
+    lpx3 = model.log_prob(x)
+    assert (np.abs(lpx3 - ref) <= tol(ref)).all() and (np.abs(lp32 - ref) <= tol(ref)).all()
+    assert not np.array_equal(lp32, lpx3)
+    model.set_option("hidden_matmul", "f32")
+    assert np.array_equal(model.log_prob(x), lp32)
+
