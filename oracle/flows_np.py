@@ -131,7 +131,7 @@ def a_nll(params, flips, y, dtype=np.float64):
 # --------------------------------------------------------------------------
 # haiku-style conditioner used by B / C / D
 # --------------------------------------------------------------------------
-def conditioner_apply(layer_params, masked_x, dtype=np.float64):
+def conditioner_apply(layer_params, masked_x, dtype=np.float64, activation="relu"):
     """hk.Sequential([Flatten, MLP(hidden, activate_final=True), Linear(P)]).
 
     ``layer_params = [(W0,b0), ..., (W_last,b_last)]``; all but the last are
@@ -139,9 +139,10 @@ def conditioner_apply(layer_params, masked_x, dtype=np.float64):
     hk.Linear (src/real_nvp_toy_densities.py:56-71, src/maf_mnist.py:34-49).
     ``masked_x`` is already flattened to [B, D].
     """
-    act = np.asarray(masked_x, dtype)
+    fn = relu if activation == "relu" else leaky_relu   # leaky_relu: not used by the reference's B/C/D
+    act = np.asarray(masked_x, dtype)                   # scripts, but the C ABI offers it for every kind
     for W, b in layer_params[:-1]:
-        act = relu(act @ np.asarray(W, dtype) + np.asarray(b, dtype))
+        act = fn(act @ np.asarray(W, dtype) + np.asarray(b, dtype))
     W, b = layer_params[-1]
     return act @ np.asarray(W, dtype) + np.asarray(b, dtype)
 
@@ -324,7 +325,7 @@ def coupling_layer(spec: FlowSpec, l: int, v, inverse: bool, dtype=np.float64):
     v = np.asarray(v, dtype)
     mask = spec.masks[l]
     masked = np.where(mask, v, dtype(0))
-    raw = conditioner_apply(spec.layers[l], masked, dtype)
+    raw = conditioner_apply(spec.layers[l], masked, dtype, getattr(spec, "activation", "relu"))
     if spec.kind == "affine":
         shift, log_scale = raw[:, :1], raw[:, 1:2]  # split(params, 2, axis=-1)
         if inverse:
@@ -791,10 +792,11 @@ def flow_nll_and_grad(spec: FlowSpec, x):
         mask = spec.masks[l]
         masked = np.where(mask, v, 0.0)
         acts, pre, a = [masked], [], masked
+        leaky = getattr(spec, "activation", "relu") != "relu"
         for W, b in spec.layers[l][:-1]:
             z = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
             pre.append(z)
-            a = relu(z)
+            a = leaky_relu(z) if leaky else relu(z)
             acts.append(a)
         W, b = spec.layers[l][-1]
         out = a @ np.asarray(W, dtype) + np.asarray(b, dtype)
@@ -830,7 +832,7 @@ def flow_nll_and_grad(spec: FlowSpec, x):
             lg.append((acts[j].T @ g, g.sum(0)))
             g = g @ W.T
             if j > 0:
-                g = g * (pre[j - 1] > 0)
+                g = g * np.where(pre[j - 1] > 0, 1.0, 0.01 if leaky else 0.0)
         grads[l] = lg[::-1]
         Gn = np.where(mask, G + g, 0.0)
         Gn[:, t_idx] = gx_t

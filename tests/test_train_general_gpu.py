@@ -245,3 +245,38 @@ def test_random_shapes_forward_and_gradient(nfa, case):
     x32, _ = O.chain_inverse(spec, z, np.float32)
     assert_close(xb, xr, f"case {case} inverse", 4 * np.abs(x32 - xr).max())
     check_grads(f, spec, x, tol=3e-4)
+
+
+@pytest.mark.parametrize("kind", ["affine", "rqs"])
+def test_leaky_relu_conditioner_forward_and_gradient(nfa, kind):
+    """The C ABI offers leaky_relu (slope 0.01, jax.nn.leaky_relu's default as in src/real_nvp.py:166)
+    for the masked kinds too; the reference's B/C/D scripts use relu, so this is the library's own
+    extension, held to the oracle like everything else."""
+    from normalizing_flows_amd import _lib
+    if kind == "affine":
+        spec = O.make_affine_spec(3, event_size=6, hidden=(40, 24), final_std=0.05)
+        kid = _lib.KIND_AFFINE_MASKED
+        extra = {}
+    else:
+        spec = O.make_rqs_spec(2, event_size=4, hidden=(32, 32), num_bins=6, range_min=-4.0, range_max=4.0,
+                               final_std=0.15)
+        kid = _lib.KIND_RQS_MASKED
+        extra = dict(rqs_bins=6, rqs_range_min=-4.0, rqs_range_max=4.0)
+    spec.activation = "leaky_relu"
+    rng = np.random.default_rng(8)
+    for layer in spec.layers:       # biases off zero so that negative pre-activations are common
+        for j in range(len(layer) - 1):
+            W, b = layer[j]
+            layer[j] = (W, (b + 0.3 * rng.standard_normal(b.shape)).astype(np.float32))
+    cfg = nfa.FlowConfig(kind=kid, event_dim=spec.event_size, num_layers=len(spec.layers),
+                         hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]), first_mask_parity=1,
+                         activation=_lib.ACT_LEAKY_RELU, **extra)
+    f = nfa.CouplingFlow(cfg, spec.layers)
+    x = (rng.standard_normal((900, spec.event_size)) * 1.5).astype(np.float32)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, "leaky_relu log_prob", 4 * e32)
+    relu_spec_lp = O.log_prob(type(spec)(spec.kind, spec.event_size, spec.layers, spec.masks, spec.base,
+                                         spec.num_bins, spec.range_min, spec.range_max), x)
+    assert np.abs(relu_spec_lp - ref).max() > 1e-3      # the activation matters on this data
+    check_grads(f, spec, x)
