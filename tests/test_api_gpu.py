@@ -367,3 +367,28 @@ def test_option_through_the_distrax_surface(distrax):
     model.set_option("hidden_matmul", "f32")
     assert np.array_equal(model.log_prob(x), lp32)
 
+
+
+def test_non_inverted_chain_and_single_coupling(distrax):
+    """Transformed(base, Chain(...)) without the Inverse wrapper (the generative direction is then
+    chain.forward and log_prob walks chain.inverse), and a single MaskedCoupling as the bijector."""
+    rng = np.random.default_rng(46)
+    model, layers = make_flow_model_affine(distrax, (2,), 5, [64, 64], rng, 0.03)
+    spec = spec_of(layers, "affine", 2)
+    base = model.distribution
+    plain = distrax.Transformed(base, distrax.Chain(layers))
+    x = O.make_inputs("energy2", 2000)
+    z, ild = O.chain_inverse(spec, x)
+    ref = O.base_log_prob(spec, z) + ild
+    got = plain.log_prob(x)
+    assert (np.abs(got - ref) <= tol(ref)).all()
+    s = plain.sample(seed=5, sample_shape=300)
+    sr, _ = O.chain_forward(spec, O.base_sample("normal", 300, 2, 5))
+    assert (np.abs(s - sr) <= 2 * tol(sr)).all()
+    one = distrax.Transformed(base, layers[2])
+    y, ld = O.coupling_layer(spec, 2, x, True)            # log_prob of Transformed(base, b) uses b.inverse
+    ref1 = O.base_log_prob(spec, y) + ld
+    assert (np.abs(one.log_prob(x) - ref1) <= tol(ref1)).all()
+    yf, ldf = layers[2].forward_and_log_det(x)
+    yr, ldr = O.coupling_layer(spec, 2, x, False)
+    assert (np.abs(yf - yr) <= tol(yr)).all() and (np.abs(ldf - ldr) <= tol(ldr)).all()
