@@ -1,0 +1,34 @@
+import sys, gc
+import numpy as np
+sys.path.insert(0, "/root/repo")
+from oracle import flows_np as O
+from normalizing_flows_amd import _lib, flow as nfa, training
+import ctypes as C
+lib = _lib.load()
+hip = C.CDLL("libamdhip64.so")
+def free_mem():
+    a, b = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(a), C.byref(b))
+    return a.value
+specs = [("affine", O.make_affine_spec(4, final_std=0.02)), ("rqs", O.make_rqs_spec(3, final_std=0.05)),
+         ("gen", O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03))]
+x2 = O.make_inputs("banana", 4096)
+x8 = np.random.default_rng(0).standard_normal((4096, 8)).astype(np.float32)
+base = None
+for it in range(60):
+    for kind, spec in specs:
+        if kind == "rqs":
+            cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=3, hidden=(64, 64), rqs_bins=12, rqs_range_min=-8.0, rqs_range_max=8.0)
+        else:
+            cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=spec.event_size, num_layers=len(spec.layers), hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]))
+        f = nfa.CouplingFlow(cfg, spec.layers)
+        x = x8 if kind == "gen" else x2
+        f.log_prob(x); f.nll(x)
+        f.set_option("hidden_matmul", "bf16x3"); f.log_prob(x)
+        f.train_step(x, training.adam(1e-4))
+        f.log_prob(x)
+        f.close()
+    gc.collect()
+    if it == 4: base = free_mem()
+    if it % 20 == 19: print("iter", it, "free MB", free_mem() / 2**20, "delta vs iter 4 (MB)", (base - free_mem()) / 2**20, flush=True)
+print("ok")
