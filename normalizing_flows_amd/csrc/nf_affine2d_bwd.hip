@@ -17,6 +17,7 @@
 // gradient in registers across all its tiles and writes it once; a second kernel adds the
 // waves' partials in a fixed order, scales by 1/rows_global and scatters into the canonical
 // (nf_flow_set_weights) layout.
+#include "nf_bf16x3.h"
 #include "nf_internal.h"
 
 #include <math.h>
@@ -28,7 +29,18 @@ namespace nf {
 namespace affine2d_bwd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+using bf16x3::bf16x8;
 constexpr int kReluShift = 64;
+
+// Image of the bf16x3 form of this kernel (hidden_matmul = bf16x3 on a training handle): the two
+// 64x64 operands as three bf16 parts each in 16-deep k steps, then the small arrays of the float32
+// image unchanged.  Built on the device from the float32 image (build_x3_image_kernel).
+constexpr int xA2 = 0;                       // [3 part][4 k16][2 mtile][64 lane][8] bf16  W2 * 2^64
+constexpr int xA2T = 6144;                   // same shape: W2 rows, k in accumulator order
+constexpr int xSmall = 12288;                // the float32 image from oW1B1 on
+constexpr int kImageFloatsX3 = xSmall + (kImageFloats - oW1B1);
+template <bool X3>
+__host__ __device__ constexpr int small_off(int o) { return X3 ? xSmall + (o - oW1B1) : o; }
 
 static inline int unit_of(int m, int r, int h) { return 32 * m + 8 * (r >> 2) + 4 * h + (r & 3); }
 
@@ -128,24 +140,32 @@ __device__ __forceinline__ float half_sum(float x) {
 constexpr int kGT = 32 * 65;          // transposed g2 tile, padded rows
 constexpr int kWaveScratch = kGT + 32;  // + the tile's conditioning values
 
+// X3: passes 1 and 3 (recompute a2; g1 = W2 g2) as six bf16 MFMAs on three-way operand splits
+// (nf_bf16x3.h); pass 4 (the weight-gradient product) and everything lane-local stay float32.
+template <bool X3>
 __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
+  constexpr int kImg = X3 ? kImageFloatsX3 : kImageFloats;
   {
     const float4* src = reinterpret_cast<const float4*>(p.img);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int q = tid; q < kImageFloats / 4; q += 256) dst[q] = src[q];
+    for (int q = tid; q < kImg / 4; q += 256) dst[q] = src[q];
   }
   __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  float* gT = lds + kImageFloats + wave * kWaveScratch;
+  float* gT = lds + kImg + wave * kWaveScratch;
   float* cbuf = gT + kGT;
   const float* L = lds;
-  const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;
+  const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;     // float32 form only
   const float2* a2t = reinterpret_cast<const float2*>(L + oA2T) + lane;
-  const float2* w1b1 = reinterpret_cast<const float2*>(L + oW1B1);
+  const bf16x8* xa2 = reinterpret_cast<const bf16x8*>(L + xA2) + lane;     // bf16x3 form: + ((part*4+s)*2+m)*64
+  const bf16x8* xa2t = reinterpret_cast<const bf16x8*>(L + xA2T) + lane;
+  const float2* w1b1 = reinterpret_cast<const float2*>(L + small_off<X3>(oW1B1));
+  constexpr int OB2 = small_off<X3>(oB2), OW3 = small_off<X3>(oW3), OB3 = small_off<X3>(oB3);
+  constexpr int OW1A = small_off<X3>(oW1acc), OB1A = small_off<X3>(oB1acc);
   const int hq = h * 32;  // offset of this half's [m][r] block in the accumulator-order images
 
   f32x16 dW2[2][2];
@@ -176,26 +196,62 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
 
     // 1. a2 = W2^T relu(w1 c + b1) + b2
     f32x16 acc[2];
-    {
-      const f32x16 bias0 = lds_f32x16(L + oB2 + hq);
-      const f32x16 bias1 = lds_f32x16(L + oB2 + hq + 16);
-      const float2 a = a2[0];
-      const float2 wb = w1b1[h];
-      const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
-    }
+    if constexpr (X3) {
+      acc[0] = lds_f32x16(L + OB2 + hq);
+      acc[1] = lds_f32x16(L + OB2 + hq + 16);
+      const float4* wb = reinterpret_cast<const float4*>(w1b1) + 4 * h;  // (w1, b1) of k = 16 s + 8 h + 0..7
+      // the operand of step s+1 (52 VALU) is issued between the 12 MFMAs of step s (one wave per
+      // SIMD here: nothing else would fill the matrix pipe's shadow)
+      bf16x8 B[2][3];
+      auto make_B = [&](int s) {
+        float hv8[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 f = wb[8 * s + k];
+          hv8[2 * k] = __builtin_amdgcn_fmed3f(fmaf(c, f.x, f.y), 0.f, 1.f);
+          hv8[2 * k + 1] = __builtin_amdgcn_fmed3f(fmaf(c, f.z, f.w), 0.f, 1.f);
+        }
+        bf16x3::split3(hv8, B[s & 1][0], B[s & 1][1], B[s & 1][2]);
+      };
+      make_B(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) make_B(s + 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          bf16x3::mfma6(acc[m], xa2[((0 * 4 + s) * 2 + m) * 64], xa2[((1 * 4 + s) * 2 + m) * 64],
+                        xa2[((2 * 4 + s) * 2 + m) * 64], B[s & 1][0], B[s & 1][1], B[s & 1][2]);
+        if (s < 3) {
+#pragma unroll
+          for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < 4) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
+      }
+    } else {
+      {
+        const f32x16 bias0 = lds_f32x16(L + OB2 + hq);
+        const f32x16 bias1 = lds_f32x16(L + OB2 + hq + 16);
+        const float2 a = a2[0];
+        const float2 wb = w1b1[h];
+        const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, bias0, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
+      }
 #pragma unroll 8
-    for (int s = 1; s < 32; ++s) {
-      const float2 a = a2[s * 64];
-      const float2 wb = w1b1[2 * s + h];
-      const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
+      for (int s = 1; s < 32; ++s) {
+        const float2 a = a2[s * 64];
+        const float2 wb = w1b1[2 * s + h];
+        const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
+      }
     }
 
     // 2. (shift, log_scale), undo the affine map, gradients of the layer's two outputs
-    const float2* w3 = reinterpret_cast<const float2*>(L + oW3) + hq;
+    const float2* w3 = reinterpret_cast<const float2*>(L + OW3) + hq;
     float ps = 0.f, pl = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -206,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
         ps = fmaf(hv, w.x, ps);
         pl = fmaf(hv, w.y, pl);
       }
-    const float shift = add_halves(ps) + L[oB3 + 0];
-    const float ls = add_halves(pl) + L[oB3 + 1];
+    const float shift = add_halves(ps) + L[OB3 + 0];
+    const float ls = add_halves(pl) + L[OB3 + 1];
     const float e = exp_f32(ls);
     const float tpm = tp - shift;
     const float t = tpm * exp_f32(-ls);            // the layer's input on the transformed dim
@@ -238,20 +294,47 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
     f32x16 g1[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { g1[0][r] = 0.f; g1[1][r] = 0.f; }
+    if constexpr (X3) {
+      bf16x8 B[2][3];
+      auto make_B = [&](int s) {  // k step (m, g) = accumulator registers acc[m][8g .. 8g+7]
+        float gv8[8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int jj = 0; jj < 8; ++jj) gv8[jj] = acc[s >> 1][8 * (s & 1) + jj];
+        bf16x3::split3(gv8, B[s & 1][0], B[s & 1][1], B[s & 1][2]);
+      };
+      make_B(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float2 a = a2t[(m * 16 + r) * 64];
-        g1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[m][r], g1[0], 0, 0, 0);
-        g1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[m][r], g1[1], 0, 0, 0);
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) make_B(s + 1);
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+          bf16x3::mfma6(g1[mo], xa2t[((0 * 4 + s) * 2 + mo) * 64], xa2t[((1 * 4 + s) * 2 + mo) * 64],
+                        xa2t[((2 * 4 + s) * 2 + mo) * 64], B[s & 1][0], B[s & 1][1], B[s & 1][2]);
+        if (s < 3) {
+#pragma unroll
+          for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          }
+        }
       }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float2 a = a2t[(m * 16 + r) * 64];
+          g1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[m][r], g1[0], 0, 0, 0);
+          g1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[m][r], g1[1], 0, 0, 0);
+        }
+    }
     float gcm = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float w1a = L[oW1acc + hq + m * 16 + r], b1a = L[oB1acc + hq + m * 16 + r];
+        const float w1a = L[OW1A + hq + m * 16 + r], b1a = L[OB1A + hq + m * 16 + r];
         const float gz = fmaf(w1a, c, b1a) > 0.f ? g1[m][r] : 0.f;
         gcm = fmaf(gz, w1a, gcm);
         db1[m][r] += gz;
@@ -347,12 +430,55 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ p
 
 int grid_blocks() { return 256; }
 
+// float32 image -> bf16x3 image, every layer in one launch (after each optimiser step the float32
+// images are refreshed by repack_kernel; this follows them)
+__global__ __launch_bounds__(256) void build_x3_image_kernel(const float* __restrict__ img32, float* __restrict__ imgx3) {
+  const float* src = img32 + (size_t)blockIdx.y * kImageFloats;
+  float* dst = imgx3 + (size_t)blockIdx.y * kImageFloatsX3;
+  unsigned short* half = reinterpret_cast<unsigned short*>(dst);
+  constexpr int kPart = 4 * 2 * 64 * 8;  // bf16 per part of one operand block
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * kPart; e += gridDim.x * 256) {
+    const int block = e / kPart, q = e % kPart;           // 0: A2, 1: A2T
+    const int j = q & 7, lane = (q >> 3) & 63, m = (q >> 9) & 1, s = q >> 10;
+    const int hk = lane >> 5, u = lane & 31;
+    float w;
+    if (block == 0) {
+      const int k = 16 * s + 8 * hk + j;                  // float32 image: k = 2 s32 + h32
+      w = src[oA2 + ((k >> 1) * 64 + (k & 1) * 32 + u) * 2 + m];
+    } else {
+      const int mk = s >> 1, r = 8 * (s & 1) + j;          // float32 image: k step (mk, r), same lane
+      w = src[oA2T + ((mk * 16 + r) * 64 + lane) * 2 + m];
+    }
+    const __bf16 hi = (__bf16)w;
+    const float r1 = w - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    unsigned short* base = half + (block == 0 ? xA2 : xA2T) * 2;
+    base[0 * kPart + q] = __builtin_bit_cast(unsigned short, hi);
+    base[1 * kPart + q] = __builtin_bit_cast(unsigned short, mid);
+    base[2 * kPart + q] = __builtin_bit_cast(unsigned short, lo);
+  }
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < kImageFloats - oW1B1; e += gridDim.x * 256)
+    dst[xSmall + e] = src[oW1B1 + e];
+}
+
+int x3_image_floats() { return kImageFloatsX3; }
+
+int launch_build_x3_images(const float* img32, float* imgx3, int num_layers, hipStream_t stream) {
+  hipLaunchKernelGGL(build_x3_image_kernel, dim3(16, num_layers), dim3(256), 0, stream, img32, imgx3);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream, int* out_parts) {
+                 hipStream_t stream, int* out_parts, bool x3) {
   static bool attr_set = false;
-  const size_t lds_bytes = (size_t)std::max(kImageFloats + 4 * kWaveScratch, 4 * kPartialFloats) * sizeof(float);
+  const int image = x3 ? kImageFloatsX3 : kImageFloats;
+  const size_t lds_bytes = (size_t)std::max(image + 4 * kWaveScratch, 4 * kPartialFloats) * sizeof(float);
   if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel),
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -367,7 +493,8 @@ int launch_layer(const float* img, float* v, float* G, float* partials, long lon
   const long long tiles = (rows + 31) / 32;
   const int grid = (int)std::min<long long>(grid_blocks(), std::max<long long>(1, (tiles + 3) / 4));
   if (out_parts) *out_parts = grid;
-  hipLaunchKernelGGL(layer_kernel, dim3(grid), dim3(256), lds_bytes, stream, p);
+  if (x3) hipLaunchKernelGGL(layer_kernel<true>, dim3(grid), dim3(256), lds_bytes, stream, p);
+  else hipLaunchKernelGGL(layer_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

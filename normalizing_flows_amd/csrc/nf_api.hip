@@ -136,6 +136,8 @@ struct nf_flow {
   struct Train {
     float *d_canon = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
     float* d_bwd_img = nullptr;     // [L][affine2d_bwd::kImageFloats]
+    float* d_bwd_img_x3 = nullptr;  // [L][x3_image_floats()], built from d_bwd_img when the handle's mode is bf16x3
+    bool bwd_x3_stale = true;
     float* d_partials = nullptr;    // [waves][kPartialFloats]
     int* d_gmap[2] = {nullptr, nullptr};      // gather maps for cond_dim 0 / 1
     float* d_gscale[2] = {nullptr, nullptr};
@@ -473,7 +475,7 @@ void nf_flow_destroy(nf_flow* f) {
   hipFree(f->d_wimg_x3);
   {
     nf_flow::Train& t = f->train;
-    hipFree(t.d_canon); hipFree(t.d_grad); hipFree(t.d_m); hipFree(t.d_v); hipFree(t.d_bwd_img);
+    hipFree(t.d_canon); hipFree(t.d_grad); hipFree(t.d_m); hipFree(t.d_v); hipFree(t.d_bwd_img); hipFree(t.d_bwd_img_x3);
     hipFree(t.d_partials); hipFree(t.d_gmap[0]); hipFree(t.d_gmap[1]); hipFree(t.d_gscale[0]);
     hipFree(t.d_gscale[1]); hipFree(t.d_fsrc); hipFree(t.d_bsrc); hipFree(t.d_fshift); hipFree(t.d_bshift);
     hipFree(t.d_state_v); hipFree(t.d_state_g);
@@ -555,6 +557,7 @@ int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
     NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
     NF_TRY(launch_repack(f->train.d_canon, f->train.d_bsrc, f->train.d_bshift, f->train.d_bwd_img,
                          (size_t)d.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    f->train.bwd_x3_stale = true;
     NF_HIP(hipStreamSynchronize(f->stream));
   }
   return NF_OK;
@@ -1033,11 +1036,22 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
     if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
     return NF_OK;
   }
+  const bool bwd_x3 = f->x3;  // the handle's matmul mode covers the backward products that feed other products
+  if (bwd_x3) {
+    const size_t per = (size_t)affine2d_bwd::x3_image_floats();
+    if (!t.d_bwd_img_x3) NF_HIP(hipMalloc(&t.d_bwd_img_x3, per * d.num_layers * sizeof(float)));
+    if (t.bwd_x3_stale) {
+      NF_TRY(affine2d_bwd::launch_build_x3_images(t.d_bwd_img, t.d_bwd_img_x3, d.num_layers, f->stream));
+      t.bwd_x3_stale = false;
+    }
+  }
   for (int l = 0; l < d.num_layers; ++l) {
     const int cond = (d.first_mask_parity + l) & 1;
     int nparts = 0;
-    NF_TRY(affine2d_bwd::launch_layer(t.d_bwd_img + (size_t)l * affine2d_bwd::kImageFloats, t.d_state_v, t.d_state_g,
-                                      t.d_partials, rows_local, cond, l == 0, f->stream, &nparts));
+    const float* image = bwd_x3 ? t.d_bwd_img_x3 + (size_t)l * affine2d_bwd::x3_image_floats()
+                                : t.d_bwd_img + (size_t)l * affine2d_bwd::kImageFloats;
+    NF_TRY(affine2d_bwd::launch_layer(image, t.d_state_v, t.d_state_g, t.d_partials, rows_local, cond, l == 0,
+                                      f->stream, &nparts, bwd_x3));
     NF_TRY(affine2d_bwd::launch_gather(t.d_partials, nparts, t.d_gmap[cond], t.d_gscale[cond],
                                        t.d_grad + (size_t)l * affine2d_bwd::kCanonFloats, rows_global, f->stream));
   }
@@ -1100,6 +1114,7 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
                          (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
     NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
                          (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    t.bwd_x3_stale = true;
   }
   if (trains_through_plan(f)) {
     NF_TRY(f->plan.refresh_from_canonical(t.d_canon, f->stream));

@@ -110,8 +110,12 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
                 const float* b3, int cond_dim, float* image);
 void build_gather_map(int cond_dim, int* map /*[kCanonFloats]*/, float* scale);
 int grid_blocks();
+// x3: `img` is this layer's bf16x3 image (x3_image_floats() each; launch_build_x3_images makes all of
+// them from the float32 images): the two products that feed other products run as bf16x3
 int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream, int* out_parts);
+                 hipStream_t stream, int* out_parts, bool x3 = false);
+int x3_image_floats();
+int launch_build_x3_images(const float* img32, float* imgx3, int num_layers, hipStream_t stream);
 int launch_gather(const float* partials, int nparts, const int* map, const float* scale, float* grad,
                   long long rows_global, hipStream_t stream);
 }  // namespace affine2d_bwd

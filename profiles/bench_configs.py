@@ -103,8 +103,9 @@ if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densiti
     cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
     f = flow.CouplingFlow(cfg, spec.layers)
     opt = training.adam(1e-4)
-    for lg in (7, 12, 20):
+    for lg, mode in [(7, "f32"), (12, "f32"), (20, "f32"), (20, "bf16x3")]:
         rows = 1 << lg
+        f.set_option("hidden_matmul", mode)
         xd = flow.DeviceArray.from_numpy(O.make_inputs("banana", rows))
         for _ in range(3):
             f.train_step(xd, opt, want_nll=False)
@@ -118,7 +119,8 @@ if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densiti
         f.synchronize()
         wall = (time.perf_counter() - t0) / steps * 1e3
         # forward 1x + backward 3x the 64x64 products (+ the small layers): 4 * 69,632 FLOP per sample
-        print(json.dumps({"config": f"train step (fwd + bwd + Adam) variant B L=8 banana batch=2^{lg}", "ms_stream": ms,
+        print(json.dumps({"config": f"train step (fwd + bwd + Adam) variant B L=8 banana batch=2^{lg}", "hidden_matmul": mode,
+                          "ms_stream": ms,
                           "ms_wall": wall, "samples_per_s": rows / ms * 1e3,
                           "TFLOPs_at_4x_forward": rows * 4 * 69632 / ms / 1e9}))
 

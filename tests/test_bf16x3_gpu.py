@@ -324,3 +324,38 @@ def test_x3_general_path_training_keeps_the_split_weights_current(nfa):
     new_spec.layers = f.get_weights()
     assert f.get_option("hidden_matmul") == "bf16x3"
     assert_close(f.log_prob(x), O.log_prob(new_spec, x), "general bf16x3 log_prob after training")
+
+
+@pytest.mark.parametrize("L,parity,rows,density", [(8, 1, 4096, "banana"), (3, 0, 1000, "energy2"), (1, 1, 33, "gaussian_blobs")])
+def test_x3_fused_affine_backward(nfa, L, parity, rows, density):
+    """With the mode on, the fused backward runs its two operand-feeding products (recompute of a2,
+    g1 = W2 g2) as bf16x3 too; the gradient holds the same 2e-4-of-the-tensor's-maximum bound."""
+    from normalizing_flows_amd import training
+    from test_parity_gpu import _flat
+    spec = O.make_affine_spec(L, final_std=0.03, first_parity=parity)
+    f = x3_flow(nfa, spec, parity)
+    x = O.make_inputs(density, rows, seed=L)
+    nll, grads = f.nll_grad(x)
+    rnll, rgrads = O.affine_nll_and_grad(spec, x)
+    assert abs(nll - rnll) <= 1e-5 * max(1.0, abs(rnll))
+    for l in range(L):
+        for j in range(3):
+            for which in (0, 1):
+                got, ref = grads[l][j][which], rgrads[l][j][which]
+                scale = max(np.abs(ref).max(), 1e-6)
+                assert np.abs(got - ref).max() <= 2e-4 * scale, (l, j, which, np.abs(got - ref).max(), scale)
+    # and the float32 form gives (slightly) different numbers: the mode did switch kernels
+    f.set_option("hidden_matmul", "f32")
+    _, g32 = f.nll_grad(x)
+    assert not np.array_equal(_flat(g32), _flat(grads))
+    # two optimiser steps under the mode follow the float64 Adam restatement
+    f.set_option("hidden_matmul", "bf16x3")
+    p = _flat([[(W.astype(np.float64), b.astype(np.float64)) for W, b in layer] for layer in spec.layers])
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for step in (1, 2):
+        f.train_step(x, training.adam(1e-3), want_nll=False)
+        cur = O.FlowSpec("affine", 2, f.unpack_weights(p), spec.masks)
+        _, rg = O.affine_nll_and_grad(cur, x)
+        p, m, v = O.adam_reference(p, _flat(rg), m, v, step, 1e-3)
+    assert np.abs(_flat(f.get_weights()) - p).max() <= 0.05 * 2 * 1e-3
