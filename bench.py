@@ -113,7 +113,10 @@ def main():
 
     lib = _lib.load()
     _lib.require_device()
-    _lib.check(lib.nf_set_device(local_rank))
+    # NF_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank uses device 0; RCCL refuses two
+    # ranks on one device, so this also exercises the gloo fallback below
+    device = 0 if os.environ.get("NF_BENCH_SHARE_GPU") == "1" else local_rank
+    _lib.check(lib.nf_set_device(device))
 
     dist = None
     comm = None
