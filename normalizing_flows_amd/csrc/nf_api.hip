@@ -432,6 +432,10 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
     if (strcmp(e, "bf16x3") == 0) {
       if (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64) f->x3 = true;
       else if (f->path == PATH_GENERIC) f->plan.x3 = true;
+    } else if (strcmp(e, "f32") != 0 && e[0] != '\0') {
+      set_error("NF_HIDDEN_MATMUL='%s': expected f32 or bf16x3", e);
+      delete f;
+      return NF_ERR_INVALID;
     }
   }
   int s = NF_OK;

@@ -290,6 +290,10 @@ def test_x3_env_default_covers_the_other_kernels(nfa, monkeypatch):
     assert s.get_option("hidden_matmul") == "f32"   # no MFMA in that kernel: the default does not apply
     monkeypatch.delenv("NF_HIDDEN_MATMUL")
     assert affine_flow(nfa, O.make_affine_spec(2, final_std=0.02)).get_option("hidden_matmul") == "f32"
+    from normalizing_flows_amd._lib import NFError
+    monkeypatch.setenv("NF_HIDDEN_MATMUL", "fp8")       # a typo must not silently mean float32
+    with pytest.raises(NFError):
+        affine_flow(nfa, O.make_affine_spec(2, final_std=0.02))
 
 
 def test_x3_spline_flow_follows_training(nfa):
