@@ -301,10 +301,13 @@ __global__ __launch_bounds__(256) void rqs_masked_bwd_kernel(const float* __rest
 // row K of the same product.  One workgroup: a 32 x 32 tile of the (K+1) x N result over one chunk
 // of rows, split between its 4 waves (8 row pairs in flight per wave) and added through LDS in a
 // fixed order.
+// grad_w != null (only with ONE row chunk): the tile is added straight into the gradient -- every element
+// belongs to exactly one workgroup -- and the separate reduction launch disappears (small batches).
 __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict__ A, int lda,
                                                          const float* __restrict__ B, int ldb,
                                                          float* __restrict__ partial, long long rows,
-                                                         long long chunk_rows, int K, int N, int tiles_n) {
+                                                         long long chunk_rows, int K, int N, int tiles_n,
+                                                         float* __restrict__ grad_w, float* __restrict__ grad_b) {
   __shared__ float red[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -337,7 +340,12 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
   for (int q = threadIdx.x; q < 1024; q += 256) {
     const int r = q >> 6, l = q & 63;
     const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), nn = n0 + (l & 31);
-    if (kk <= K && nn < N) out[(size_t)kk * N + nn] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+    if (kk <= K && nn < N) {
+      const float t = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+      if (grad_w == nullptr) out[(size_t)kk * N + nn] = t;
+      else if (kk < K) grad_w[(size_t)kk * N + nn] += t;
+      else grad_b[nn] += t;
+    }
   }
 }
 
@@ -379,10 +387,15 @@ static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long 
   long long chunk_rows = (rows + nchunks - 1) / nchunks;
   chunk_rows = (chunk_rows + 1) & ~1LL;
   nchunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-  hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, nchunks), dim3(256), 0, stream, A, lda, B, ldb,
-                     partials, rows, chunk_rows, K, N, tiles_n);
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, partials, nchunks,
-                     (size_t)K * N, (size_t)N, grad_w, grad_b);
+  if (nchunks == 1) {
+    hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, 1), dim3(256), 0, stream, A, lda, B, ldb, partials,
+                       rows, chunk_rows, K, N, tiles_n, grad_w, grad_b);
+  } else {
+    hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, nchunks), dim3(256), 0, stream, A, lda, B, ldb,
+                       partials, rows, chunk_rows, K, N, tiles_n, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, partials, nchunks,
+                       (size_t)K * N, (size_t)N, grad_w, grad_b);
+  }
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
