@@ -61,12 +61,13 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(spec, density):
+def cpu_baseline(layers, density):
     """The C restatement of the oracle (oracle/nf_oracle.c, OpenMP over the batch) timed on
     this host's cores: a reported baseline ("port"), not the target.  Bounded sample of the
-    same workload (about 10 s)."""
+    same workload (about 10 s).  The ONLY place this file touches oracle/."""
     from oracle import c_oracle as CO
     from oracle import flows_np as O
+    spec = O.FlowSpec("affine", 2, layers, O.alternating_masks(2, len(layers), 1))
     rows = 1 << 20
     x = O.make_inputs(density, rows)
     threads = min(CO.max_threads(), usable_cpus())
@@ -108,8 +109,8 @@ def main():
                      "--nproc-per-node N (one rank per GPU)")
         args.gpus = world
 
-    from normalizing_flows_amd import _lib, flow
-    from oracle import flows_np as O   # synthetic weights/inputs + the cpu_baseline leg only
+    from normalizing_flows_amd import _lib, densities, flow
+    from normalizing_flows_amd.conditioner import make_conditioner
 
     lib = _lib.load()
     _lib.require_device()
@@ -136,18 +137,21 @@ def main():
             comm.close()
             comm, rccl_error = None, "another rank failed to initialise RCCL"
 
-    spec = O.make_affine_spec(args.layers, final_std=0.02)
+    # synthetic weights (random init of the architecture: haiku's truncated-normal hidden layers, a small
+    # non-zero last Linear so that the flow is not the identity), the same on every rank
+    layers = [make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(534 + l), final_std=0.02).linears
+              for l in range(args.layers)]
     cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=args.layers, hidden=(64, 64))
-    f = flow.CouplingFlow(cfg, spec.layers)
+    f = flow.CouplingFlow(cfg, layers)
     if comm is not None:
         f.attach_comm(comm)
     f.set_option("hidden_matmul", args.hidden_matmul)
 
     rows = args.rows
     rows_global = rows * world
-    # every rank owns its own rows of the global batch (different seed per rank)
-    x = O.make_inputs(args.density, rows, seed=2123 + rank)
-    xd = flow.DeviceArray.from_numpy(x)
+    # every rank owns its own rows of the global batch (different seed per rank), drawn on the device by
+    # the library's density generator (src/densities/*.py restated, nf_density_sample): resident in HBM
+    xd = next(densities.get_density(args.density)(seed=2123 + rank, batch_size=rows, num_batches=1, device=True))
     lpd = flow.DeviceArray((rows,))
 
     def barrier():
@@ -234,7 +238,7 @@ def main():
         if variant is not None:
             out["variants"] = [variant]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(spec, args.density)
+            out["cpu_baseline"] = cpu_baseline(layers, args.density)
         print(json.dumps(out))
 
     if dist is not None:

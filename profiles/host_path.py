@@ -3,7 +3,7 @@ model.log_prob(batch) costs a script that keeps its data in host memory.  python
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import flows_np as O
+import _synthetic as O  # product generators; the oracle is not used here
 from normalizing_flows_amd import _lib, flow as nfa
 
 spec = O.make_affine_spec(8, final_std=0.02)

@@ -1,7 +1,8 @@
 import sys, gc
 import numpy as np
 sys.path.insert(0, "/root/repo")
-from oracle import flows_np as O
+sys.path.insert(0, "/root/repo/profiles")
+import _synthetic as O  # product generators
 from normalizing_flows_amd import _lib, flow as nfa, training
 import ctypes as C
 lib = _lib.load()

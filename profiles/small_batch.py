@@ -2,7 +2,7 @@
 evaluates at batch 128), 8 layers, both hidden_matmul modes.   python profiles/small_batch.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import flows_np as O
+import _synthetic as O  # product generators; the oracle is not used here
 from normalizing_flows_amd import _lib, flow as nfa
 
 spec = O.make_affine_spec(8, final_std=0.02)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 def one():
-    from oracle import flows_np as O
+    import _synthetic as O  # product generators; the oracle is not used here
     from normalizing_flows_amd import _lib, flow as nfa
     spec = O.make_affine_spec(8, final_std=0.02)
     cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), first_mask_parity=1)

@@ -242,7 +242,7 @@ def x3_default(monkeypatch, nfa):
     errors, whose ratio on single ill-conditioned samples scatters (the one case beyond 4: a
     one-layer inverse at a point with |dx/dz| = 33 where this mode is 1.16e-4 from float64, the
     exact kernel 0.69e-4 and NumPy float32 0.27e-4); rms errors of the two modes are equal
-    (test_x3_log_prob_l8, profiles/x3_error_stats.py)."""
+    (test_x3_log_prob_l8, tests/tools/x3_error_stats.py)."""
     monkeypatch.setenv("NF_HIDDEN_MATMUL", "bf16x3")
     monkeypatch.setattr(P, "FLOOR", 6.0)
     spec = O.make_rqs_spec(1, final_std=0.05)

@@ -1,8 +1,8 @@
 """Error of the two hidden-matmul modes against the float64 oracle (development aid).
-usage: python profiles/x3_error_stats.py   (GPU box)"""
+usage: python tests/tools/x3_error_stats.py   (GPU box).  Lives under tests/: it uses the oracle as the checker."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import flows_np as O
 from normalizing_flows_amd import _lib, flow as nfa
 
