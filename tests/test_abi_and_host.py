@@ -257,3 +257,33 @@ def test_prepare_data_matches_the_reference_arithmetic():
     assert np.array_equal(noisy, prepare_data(img, prng_key=42))          # reproducible, accepts the array itself
     assert not np.array_equal(noisy, prepare_data(img, prng_key=43))
 
+
+
+def test_oracle_is_used_only_where_it_may_be():
+    """oracle/ is test infrastructure: outside tests/ only __graft_entry__.smoke() and bench.py's
+    cpu_baseline() may import it -- not the package, not the examples, not the measurement scripts."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        found = []
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                found.append(node.lineno)
+        return tree, found
+
+    for pattern in ("normalizing_flows_amd/*.py", "examples/*.py", "profiles/*.py", "profiles/scratch/*.py"):
+        for path in glob.glob(os.path.join(root, pattern)):
+            assert oracle_imports(path)[1] == [], path
+    for path, allowed in ((os.path.join(root, "bench.py"), "cpu_baseline"),
+                          (os.path.join(root, "__graft_entry__.py"), "smoke")):
+        tree, lines = oracle_imports(path)
+        fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == allowed)
+        assert lines and all(fn.lineno <= ln <= fn.end_lineno for ln in lines), (path, lines)
