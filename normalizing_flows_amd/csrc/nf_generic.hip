@@ -942,6 +942,17 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       const float* a = yc;
       int lda = D;
       if (d.kind == NF_KIND_AFFINE_SPLIT && par) a = yc + D / 2;  // flipped: second half conditions
+      const Linear* Ls = &linears[(size_t)l * nlin];
+      if (!(x3 && d_wx3) && mlp_small_applicable(Ls, nlin)) {
+        // narrow conditioner: one launch, activations stay in LDS (recorded only for the training walk)
+        float* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < nlin; ++j) {
+          if (record_tape) outs[j] = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * Ls[j].N;
+          else if (j == nlin - 1) outs[j] = buf[2];
+        }
+        NF_TRY(launch_mlp_small(a, lda, Ls, nlin, d_weights, act, outs, n, stream));
+        a = outs[nlin - 1];
+      } else
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];

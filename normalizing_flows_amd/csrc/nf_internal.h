@@ -235,6 +235,10 @@ struct Plan {
   // y [rows, D] and ld [rows] hold the chain's input state and are updated in place
   int walk(float* y, float* ld, const ChainIO& io, hipStream_t stream);
 };
+// nf_mlp_small.hip: a whole conditioner (every Linear K, N <= 64) in one launch
+bool mlp_small_applicable(const Linear* Ls, int nlin);
+int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights, int act,
+                     float* const* outs, long long rows, hipStream_t stream);
 size_t x3_image_halfwords(int K, int N);
 void pack_w_x3(const float* W /*[K][N]*/, int K, int N, unsigned short* image);
 bool gemm_x3_applicable(const float* A, int lda, int N, int K);
