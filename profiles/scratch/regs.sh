@@ -2,7 +2,7 @@
 # usage: regs.sh <file.hip> [extra flags]  -> per-kernel vgpr/scratch summary + instruction counts
 f=$1; shift
 b=$(basename $f .hip)
-cd /root/repo/normalizing_flows_amd/csrc
+cd "$(dirname "$0")/../../normalizing_flows_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-function -fno-honor-nans -fno-slp-vectorize "$@" -c $f -o /tmp/$b.o -save-temps=obj 2>&1 | grep -E "error"
 python3 - /tmp/$b-hip-amdgcn-amd-amdhsa-gfx950.s <<'PY'
 import re,sys,collections

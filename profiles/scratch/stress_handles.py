@@ -1,7 +1,8 @@
-import sys, gc
+import os, sys, gc
 import numpy as np
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, "/root/repo/profiles")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
 import _synthetic as O  # product generators
 from normalizing_flows_amd import _lib, flow as nfa, training
 import ctypes as C

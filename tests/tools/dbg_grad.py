@@ -1,6 +1,7 @@
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import flows_np as O
 from normalizing_flows_amd import _lib, flow as nfa
 np.set_printoptions(linewidth=220, precision=5, suppress=True)

@@ -1,6 +1,7 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from oracle import flows_np as O
 from normalizing_flows_amd import _lib, flow as nfa
 K, L, parity, rows, lo, hi = 12, 1, 0, 33, -8.0, 8.0
