@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
 #undef NF_STASH
 
 int max_grid() { return 256; }
-bool supported_bins(int K) { return K == 12 || K == 8 || K == 4; }
+bool supported_bins(int K) { return K == 12 || K == 10 || K == 8 || K == 6 || K == 4; }
 
 template <int T, int WAVES, int INV, int K>
 static int launch_t(const Params& p, int grid, hipStream_t stream) {
@@ -300,9 +300,11 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   if (out_grid) *out_grid = grid;
   switch (d.rqs_bins) {
     case 12: return launch_k<12>(p, grid, T, waves, stream);
+    case 10: return launch_k<10>(p, grid, T, waves, stream);
     case 8: return launch_k<8>(p, grid, T, waves, stream);
+    case 6: return launch_k<6>(p, grid, T, waves, stream);
     case 4: return launch_k<4>(p, grid, T, waves, stream);
-    default: set_error("rqs2d kernel is built for 4, 8 and 12 bins"); return NF_ERR_UNSUPPORTED;
+    default: set_error("rqs2d kernel is built for 4, 6, 8, 10 and 12 bins"); return NF_ERR_UNSUPPORTED;
   }
 }
 

@@ -258,7 +258,8 @@ def test_x3_rqs_toy_config3(nfa, x3_default, density):
 
 @pytest.mark.parametrize("K,L,parity,rows,lo,hi", [(12, 8, 1, 4096, -8.0, 8.0), (12, 1, 0, 33, -8.0, 8.0),
                                                    (8, 3, 1, 1000, -5.0, 5.0), (4, 5, 0, 70001, -3.0, 4.0),
-                                                   (12, 11, 1, 513, -8.0, 8.0)])
+                                                   (12, 11, 1, 513, -8.0, 8.0), (6, 4, 1, 777, -6.0, 6.0),
+                                                   (10, 2, 0, 2049, -8.0, 8.0)])
 def test_x3_rqs_fused_kernel_shapes(nfa, x3_default, K, L, parity, rows, lo, hi):
     P.test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi)
 

@@ -512,7 +512,8 @@ def test_golden_vectors(nfa):
 # ------------------------------------------------------------------ fused spline kernel (D = 2, 64-wide)
 @pytest.mark.parametrize("K,L,parity,rows,lo,hi", [(12, 8, 1, 4096, -8.0, 8.0), (12, 1, 0, 33, -8.0, 8.0),
                                                    (8, 3, 1, 1000, -5.0, 5.0), (4, 5, 0, 70001, -3.0, 4.0),
-                                                   (12, 11, 1, 513, -8.0, 8.0)])
+                                                   (12, 11, 1, 513, -8.0, 8.0), (6, 4, 1, 777, -6.0, 6.0),
+                                                   (10, 2, 0, 2049, -8.0, 8.0)])
 def test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi):
     from normalizing_flows_amd import _lib
     spec = O.make_rqs_spec(L, num_bins=K, range_min=lo, range_max=hi, final_std=0.05, first_parity=parity)
