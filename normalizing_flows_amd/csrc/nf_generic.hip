@@ -93,7 +93,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
     __syncthreads();
     if (k0 + BK < K) fetch(k0 + BK);
     const int steps = ((K - k0 < BK ? K - k0 : BK) + 1) / 2;  // a short K (first Linear of a 2-D flow: 2) stops early
-#pragma unroll 4
     for (int s = 0; s < steps; ++s) {
       float a[TM], b[TN];
 #pragma unroll

@@ -73,14 +73,12 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
       if (ntiles > 1) {
-#pragma unroll 4
         for (int s = 0; s < steps; ++s) {
           const float av = T[i * kTileStride + 2 * s + h];
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(2 * s + h) * 64 + i], acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(2 * s + h) * 64 + 32 + i], acc[1], 0, 0, 0);
         }
       } else {
-#pragma unroll 4
         for (int s = 0; s < steps; ++s)
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(T[i * kTileStride + 2 * s + h], Ws[(2 * s + h) * 64 + i],
                                                         acc[0], 0, 0, 0);
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
       const int act = a.act[j];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        if (u >= ntiles) break;
+        if (u >= ntiles) continue;
         const int n = 32 * u + i;
         const float bias = bs[n];
 #pragma unroll
