@@ -138,21 +138,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bias_act_kernel(
 constexpr int FBM = 128, FBN = 128, FBK = 32;
 constexpr int kFastLdsFloats = FBM * (FBK + 1) + FBK * FBN;  // one 33 KB stage: four workgroups per CU
 
-__global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy, const float* __restrict__ aux) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// The k loop shared by gemm_fast_kernel and gemm_rqs_kernel: acc[t][u] = the wave's 2 x 2 tiles of
+// A[m0.., :] @ W[:, n0..] (no bias).  Ends with a barrier: smem is free again.
+__device__ __forceinline__ void gemm_fast_mainloop(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                   int M, int N, int K, int m0, int n0, float* smem,
+                                                   f32x16 (&acc)[2][2]) {
   constexpr int kAs = FBM * (FBK + 1);  // A tile, then the W tile
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int m0 = (id / gx) * FBM, n0 = (id % gx) * FBN;
-
   // this thread's share of a k-tile: A rows ar + 32 e (e < 4), k quad akq; W rows wk + 8 e, col quad wc
   const int ar = tid >> 3, akq = (tid & 7) * 4;
   const int wk = tid >> 5, wc = (tid & 31) * 4;
@@ -176,8 +171,6 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
       *reinterpret_cast<float4*>(smem + kAs + (wk + 8 * e) * FBN + wc) = rw[e];
     }
   };
-
-  f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -208,6 +201,22 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
       __syncthreads();
     }
   }
+}
+
+__global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy, const float* __restrict__ aux) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+  const int m0 = (id / gx) * FBM, n0 = (id % gx) * FBN;
+  f32x16 acc[2][2];
+  gemm_fast_mainloop(A, lda, W, M, N, K, m0, n0, smem, acc);
 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -564,6 +573,134 @@ static bool launch_rqs_rows(float* y, float* ld, const float* params, long long 
   return true;
 }
 
+// ------------------------------------------------------------------------
+// SURVEY's K5: the last Linear of a spline layer with the spline in its epilogue -- the
+// [rows, Dt * (3K+1)] parameter tensor (2.6 GB per layer at the MNIST shape) never reaches HBM.
+// Columns are laid out so that a 128-column block holds PPB = 128 / (3K+1) whole transformed dims
+// (Plan::build_k5); the block's 128 x 128 result goes through LDS in two 64-row halves, every thread
+// takes (row, dim) items and applies rqs_eval_reg to y in place; a row's log-dets of the block's dims
+// are added in dim order and written to ldpart[column block][row]; ld_reduce_kernel adds the
+// column blocks in order.
+// ------------------------------------------------------------------------
+constexpr int kCtStride = 129;
+constexpr int kRqsLdsFloats = (kFastLdsFloats > 64 * kCtStride ? kFastLdsFloats : 64 * kCtStride) + 64 * 8;
+
+template <int K, int INV>
+__global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ y, float* __restrict__ ldpart, int M,
+                                                          int Npad, int Kdim, int D, int pass_parity, int gx, int gy,
+                                                          RqsConst c) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int P = 3 * K + 1, PPB = 128 / P;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+  const int mb = id / gx, nb = id % gx;
+  const int m0 = mb * FBM, n0 = nb * FBN;
+  f32x16 acc[2][2];
+  gemm_fast_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);
+
+  const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
+  const int first_t = pass_parity == 0 ? 1 : 0;
+  float* Ct = smem;                       // [64][kCtStride]
+  float* ldl = smem + kRqsLdsFloats - 64 * 8;  // [64][8]
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = wn * 64 + u * 32 + i;
+          const float bv = bias[n0 + col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Ct[(t * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * kCtStride + col] = acc[t][u][r] + bv;
+        }
+    }
+    __syncthreads();
+    for (int item = tid; item < 64 * PPB; item += 256) {
+      const int r = item & 63, px = item >> 6;
+      const int t_global = nb * PPB + px;
+      const long long row = (long long)m0 + half * 64 + r;
+      float l = 0.f;
+      if (t_global < Dt && row < M) {
+        float* yp = y + row * D + first_t + 2 * t_global;
+        float res;
+        rqs_eval_reg<K, INV>(Ct + r * kCtStride + px * P, c, *yp, &res, &l);
+        *yp = res;
+      }
+      ldl[r * 8 + px] = l;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const long long row = (long long)m0 + half * 64 + tid;
+      if (row < M) {
+        float sum = 0.f;
+#pragma unroll
+        for (int px = 0; px < PPB; ++px) sum += ldl[tid * 8 + px];
+        ldpart[(size_t)nb * M + row] = sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void ld_reduce_kernel(const float* __restrict__ ldpart, int nblocks, long long rows,
+                                                        float* __restrict__ ld) {
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += ldpart[(size_t)b * rows + r];
+    ld[r] += s;
+  }
+}
+
+// W[k][ (t * P + q) ] (pruned, dense) -> Wk5[k][ (t / PPB) * 128 + (t % PPB) * P + q ], zero elsewhere; row
+// `Kdim` of the destination is the bias
+__global__ __launch_bounds__(256) void k5_layout_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                        float* __restrict__ Wk5, float* __restrict__ bk5, int Kdim,
+                                                        int N, int Npad, int P, int PPB) {
+  const long long total = (long long)(Kdim + 1) * Npad;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int k = (int)(q / Npad), col = (int)(q % Npad);
+    const int blk = col >> 7, in = col & 127, px = in / P, pq = in % P;
+    const int src = (blk * PPB + px) * P + pq;
+    const bool live = px < PPB && src < N;
+    if (k < Kdim) Wk5[(size_t)k * Npad + col] = live ? W[(size_t)k * N + src] : 0.f;
+    else bk5[col] = live ? b[src] : 0.f;
+  }
+}
+
+template <int K>
+static int launch_gemm_rqs(const float* A, int lda, const float* Wk5, const float* bk5, float* y, float* ldpart,
+                           float* ld, int M, int Npad, int Kdim, int D, int par, int inverse, const RqsConst& rc,
+                           hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rqs_kernel<K, 0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rqs_kernel<K, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
+  const int gx = Npad / FBN, gy = (M + FBM - 1) / FBM;
+  const size_t lds = kRqsLdsFloats * sizeof(float);
+  if (inverse)
+    hipLaunchKernelGGL((gemm_rqs_kernel<K, 1>), dim3(gx * gy), dim3(256), lds, stream, A, lda, Wk5, bk5, y, ldpart, M,
+                       Npad, Kdim, D, par, gx, gy, rc);
+  else
+    hipLaunchKernelGGL((gemm_rqs_kernel<K, 0>), dim3(gx * gy), dim3(256), lds, stream, A, lda, Wk5, bk5, y, ldpart, M,
+                       Npad, Kdim, D, par, gx, gy, rc);
+  hipLaunchKernelGGL(ld_reduce_kernel, dim3((unsigned)std::min<long long>(4096, ((long long)M + 255) / 256)), dim3(256), 0,
+                     stream, ldpart, gx, (long long)M, ld);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // log_prob = base log-density(z) + logdet; optional float64 block sums.
 __global__ __launch_bounds__(256) void base_log_prob_kernel(const float* __restrict__ z, const float* __restrict__ ld,
                                                            float* __restrict__ lp, double* __restrict__ block_sums,
@@ -825,7 +962,39 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
   NF_HIP(hipMemcpy(d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   host_weights.swap(host);
+  // K5: the last Linear of a spline layer through gemm_rqs_kernel
+  k5 = false;
+  if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
+  if (d.kind == NF_KIND_RQS_MASKED && getenv("NF_NO_K5") == nullptr &&
+      (d.rqs_bins == 6 || d.rqs_bins == 8 || d.rqs_bins == 10 || d.rqs_bins == 12)) {
+    const Linear& last = linears[nlin - 1];
+    const int ppb = 128 / P;
+    int dt_max = (d.event_dim + 1) / 2;
+    if ((last.K & 3) == 0 && last.K >= 32 && !(last.K <= 64 && last.N <= 64)) {
+      k5_npad = ((dt_max + ppb - 1) / ppb) * 128;
+      k5_layer_floats = (size_t)(last.K + 1) * k5_npad;
+      NF_HIP(hipMalloc(&d_wk5, k5_layer_floats * d.num_layers * sizeof(float)));
+      k5 = true;
+      NF_TRY(refresh_k5(nullptr));
+      NF_HIP(hipDeviceSynchronize());
+    }
+  }
   if (x3) return set_x3(true);  // new weights under an option that was already on
+  return NF_OK;
+}
+
+int Plan::refresh_k5(hipStream_t stream) {
+  if (!k5) return NF_OK;
+  const int nlin = desc.num_hidden + 1, P = 3 * desc.rqs_bins + 1, ppb = 128 / P;
+  for (int l = 0; l < desc.num_layers; ++l) {
+    const Linear& L = linears[(size_t)l * nlin + nlin - 1];
+    float* dst = d_wk5 + (size_t)l * k5_layer_floats;
+    const long long total = (long long)(L.K + 1) * k5_npad;
+    hipLaunchKernelGGL(k5_layout_kernel, dim3((unsigned)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
+                       stream, d_weights + L.w_off, d_weights + L.b_off, dst, dst + (size_t)L.K * k5_npad, L.K, L.N,
+                       k5_npad, P, ppb);
+  }
+  NF_HIP(hipGetLastError());
   return NF_OK;
 }
 
@@ -850,6 +1019,8 @@ int Plan::set_x3(bool on) {
 
 void Plan::release() {
   if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
+  if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
+  k5 = false;
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
   bwd = Backward();
@@ -864,7 +1035,7 @@ int Plan::ensure_scratch(long long rows) {
   // per row: two activation ping-pong buffers + the conditioner's output; up to 4 GiB of the
   // 288 GB so that even the 784-D flow walks 2^16 rows in one chunk (big M keeps the GEMMs of the
   // narrow hidden layers at full occupancy)
-  const size_t per_row = ((size_t)2 * act_width + param_width) * sizeof(float);
+  const size_t per_row = ((size_t)2 * act_width + param_width + (k5 ? k5_npad / 128 : 0)) * sizeof(float);
   long long cap = (long long)(((size_t)4 << 30) / per_row);
   cap = std::max<long long>(128, cap / 128 * 128);
   const long long want = std::min(rows, cap);
@@ -942,6 +1113,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       int lda = D;
       if (d.kind == NF_KIND_AFFINE_SPLIT && par) a = yc + D / 2;  // flipped: second half conditions
       const Linear* Ls = &linears[(size_t)l * nlin];
+      bool fused_transform = false;
       if (!(x3 && d_wx3) && mlp_small_applicable(Ls, nlin)) {
         // narrow conditioner: one launch, activations stay in LDS (recorded only for the training walk)
         float* outs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -954,6 +1126,22 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       } else
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
+        if (j == nlin - 1 && k5 && !record_tape && !(x3 && d_wx3) && (lda & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
+          // K5: GEMM + spline in one kernel; theta stays in LDS
+          const float* wk = d_wk5 + (size_t)l * k5_layer_floats;
+          float* ldpart = d_scratch + ((size_t)2 * act_width + param_width) * scratch_rows;
+          int st = NF_ERR_UNSUPPORTED;
+          switch (rc.K) {
+            case 6: st = launch_gemm_rqs<6>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;
+            case 8: st = launch_gemm_rqs<8>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;
+            case 10: st = launch_gemm_rqs<10>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;
+            case 12: st = launch_gemm_rqs<12>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;
+          }
+          NF_TRY(st);
+          fused_transform = true;
+          break;
+        }
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
         if (record_tape)  // training: every Linear's output stays (hidden activations and theta)
           dst = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * L.N;
@@ -966,7 +1154,8 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         a = dst;
         lda = L.N;
       }
-      NF_TRY(launch_transform(d, yc, ldc, a /* the last Linear's output */, n, par, io.inverse_op, rc, stream));
+      if (!fused_transform)
+        NF_TRY(launch_transform(d, yc, ldc, a /* the last Linear's output */, n, par, io.inverse_op, rc, stream));
       NF_HIP(hipGetLastError());
     }
   }

@@ -221,6 +221,13 @@ struct Plan {
     float* d_acts = nullptr;         // every Linear's output of that walk: [tape_rows][N] at act_off[layer*nlin+j]
     std::vector<size_t> act_off;
   } bwd;
+  // SURVEY's K5 (spline layers whose last Linear is wide enough for the MFMA GEMM): weights of that Linear
+  // re-laid so that a 128-column block holds whole transformed dims; the spline runs in the GEMM epilogue
+  bool k5 = false;
+  float* d_wk5 = nullptr;            // per layer: [Kdim][k5_npad] then the bias [k5_npad]
+  size_t k5_layer_floats = 0;
+  int k5_npad = 0;
+  int refresh_k5(hipStream_t stream);  // from d_weights (after build and after every optimiser step)
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
   int prepare_backward();            // after build(): index map, transposes, buffers
