@@ -20,6 +20,7 @@
 // registers, three workgroups per CU (144 KiB of LDS, <= 168 registers).
 #include "nf_bf16x3.h"
 #include "nf_internal.h"
+#include "nf_rqs_eval.h"
 
 #include <math.h>
 #include <string.h>
@@ -61,11 +62,10 @@ void pack_w_x3(const float* W, int K, int N, unsigned short* img) {
 }
 
 // ---- device ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int lda,
-                                                         const uint4* __restrict__ Wimg,
-                                                         const float* __restrict__ bias, float* __restrict__ Cm,
-                                                         int ldc, int M, int N, int K, int act, int gx, int gy) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
+// The k loop shared by gemm_x3_kernel and gemm_x3_rqs_kernel: acc[t][u] = the wave's 2 x 2 tiles of
+// A[m0.., :] @ W[:, 128 nb ..]; returns after a barrier (LDS free).
+__device__ __forceinline__ void gemm_x3_mainloop(const float* __restrict__ A, int lda, const uint4* __restrict__ Wimg,
+                                                 int M, int K, int m0, int nb, uint4* lds_u4, f32x16 (&acc)[2][2]) {
   uint4* As = lds_u4;             // [part 3][k16 2][row 128][2]   (2 uint4 = 16 bf16 per row)
   uint4* Ws = lds_u4 + kTileU4;   // [part 3][k16 2][ntile 4][lane 64]
 
@@ -73,11 +73,6 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // one XCD sees a contiguous run of tiles
-  const int mb = id / gx, nb = id % gx;
-  const int m0 = mb * XBM, n0 = nb * XBN;
   const int nk = (K + XBK - 1) / XBK;
 
   // this thread's share of an A tile: row arow, k = 16 ks + 8 akq + 0..7 for ks = 0, 1 -- so that the
@@ -122,7 +117,6 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
     Ws[tid + 768] = rw3; Ws[tid + 1024] = rw4; Ws[tid + 1280] = rw5;                \
   }
 
-  f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -161,6 +155,24 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
 #undef NF_FETCH
 #undef NF_SPLIT4
 #undef NF_STASH
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int lda,
+                                                         const uint4* __restrict__ Wimg,
+                                                         const float* __restrict__ bias, float* __restrict__ Cm,
+                                                         int ldc, int M, int N, int K, int act, int gx, int gy) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // one XCD sees a contiguous run of tiles
+  const int mb = id / gx, nb = id % gx;
+  const int m0 = mb * XBM, n0 = nb * XBN;
+  f32x16 acc[2][2];
+  gemm_x3_mainloop(A, lda, Wimg, M, K, m0, nb, lds_u4, acc);
 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -179,6 +191,66 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
         Cm[(size_t)row * ldc + col] = v;
       }
     }
+}
+
+// SURVEY's K5 under the mode: the last Linear of a spline layer (weights in Plan's K5 column layout,
+// split image) with the spline in the epilogue (rqs_tile_epilogue, nf_rqs_eval.h).
+template <int KB, int INV>
+__global__ __launch_bounds__(256, 3) void gemm_x3_rqs_kernel(const float* __restrict__ A, int lda,
+                                                             const uint4* __restrict__ Wimg,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             float* __restrict__ ldpart, int M, int K, int D,
+                                                             int pass_parity, int gx, int gy, RqsConst c) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+  const int mb = id / gx, nb = id % gx;
+  const int m0 = mb * XBM, n0 = nb * XBN;
+  f32x16 acc[2][2];
+  gemm_x3_mainloop(A, lda, Wimg, M, K, m0, nb, lds_u4, acc);
+  float* smem = reinterpret_cast<float*>(lds_u4);
+  static_assert(2 * kTileU4 * 16 >= (64 * kCtStride + 64 * 8) * 4, "epilogue tile must fit the GEMM's LDS stage");
+  rqs_tile_epilogue<KB, INV>(acc, bias, n0, m0, nb, M, D, pass_parity, y, ldpart, smem, smem + 64 * kCtStride, c);
+}
+
+template <int KB>
+static int launch_gemm_x3_rqs_k(const float* A, int lda, const unsigned short* wimg, const float* bias, float* y,
+                                float* ldpart, int M, int Npad, int K, int D, int par, int inverse,
+                                const RqsConst& rc, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds_bytes = 2 * (size_t)kTileU4 * sizeof(uint4);
+  if (!attr_set) {
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_rqs_kernel<KB, 0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_rqs_kernel<KB, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  const int gx = Npad / XBN, gy = (M + XBM - 1) / XBM;
+  const uint4* w = reinterpret_cast<const uint4*>(wimg);
+  if (inverse)
+    hipLaunchKernelGGL((gemm_x3_rqs_kernel<KB, 1>), dim3(gx * gy), dim3(256), lds_bytes, stream, A, lda, w, bias, y,
+                       ldpart, M, K, D, par, gx, gy, rc);
+  else
+    hipLaunchKernelGGL((gemm_x3_rqs_kernel<KB, 0>), dim3(gx * gy), dim3(256), lds_bytes, stream, A, lda, w, bias, y,
+                       ldpart, M, K, D, par, gx, gy, rc);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+// ldpart [Npad / 128][M]: the caller adds the column blocks' log-dets in order (ld_reduce_kernel)
+int launch_gemm_x3_rqs(const float* A, int lda, const unsigned short* wimg, const float* bias, float* y,
+                       float* ldpart, int M, int Npad, int K, int D, int par, int inverse, const RqsConst& rc,
+                       hipStream_t stream) {
+  switch (rc.K) {
+    case 6: return launch_gemm_x3_rqs_k<6>(A, lda, wimg, bias, y, ldpart, M, Npad, K, D, par, inverse, rc, stream);
+    case 8: return launch_gemm_x3_rqs_k<8>(A, lda, wimg, bias, y, ldpart, M, Npad, K, D, par, inverse, rc, stream);
+    case 10: return launch_gemm_x3_rqs_k<10>(A, lda, wimg, bias, y, ldpart, M, Npad, K, D, par, inverse, rc, stream);
+    case 12: return launch_gemm_x3_rqs_k<12>(A, lda, wimg, bias, y, ldpart, M, Npad, K, D, par, inverse, rc, stream);
+  }
+  set_error("no fused spline epilogue for %d bins", rc.K);
+  return NF_ERR_UNSUPPORTED;
 }
 
 bool gemm_x3_applicable(const float* A, int lda, int N, int K) {

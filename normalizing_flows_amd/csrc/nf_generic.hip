@@ -14,6 +14,7 @@
 // parameters of the transformed dims are computed (the others are never read by
 // distrax.MaskedCoupling either: y = where(mask, x, y0)).
 #include "nf_internal.h"
+#include "nf_rqs_eval.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -420,86 +421,6 @@ __global__ __launch_bounds__(256) void rqs_masked_kernel(float* __restrict__ y, 
 // parameters through LDS with coalesced 16-byte loads (a lane's 3K+1 values are then a stride-(3K+1)
 // LDS read: odd stride, conflict-free), evaluates one (row, transformed dim) pair per thread and
 // iteration with everything in registers, and reduces each row's log-dets in a fixed order.
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
-__device__ __forceinline__ float softplus_fast(float v) {
-  return fmaxf(v, 0.f) + flog(1.f + fexp2(-fabsf(v) * 1.44269504f));
-}
-
-template <int K, int INV>
-__device__ __forceinline__ void rqs_eval_reg(const float* __restrict__ p, const RqsConst& c, float v, float* out,
-                                             float* logdet) {
-  constexpr float kL2E = 1.44269504f;
-  const float total = c.range_max - c.range_min;
-  float lw[K], lh[K];
-  float mw = -INFINITY, mh = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < K; ++k) { lw[k] = p[k]; lh[k] = p[K + k]; mw = fmaxf(mw, lw[k]); mh = fmaxf(mh, lh[k]); }
-  float sw = 0.f, sh = 0.f;
-  const float mwl = -mw * kL2E, mhl = -mh * kL2E;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    lw[k] = fexp2(fmaf(lw[k], kL2E, mwl)); sw += lw[k];
-    lh[k] = fexp2(fmaf(lh[k], kL2E, mhl)); sh += lh[k];
-  }
-  const float scw = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sw);
-  const float sch = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sh);
-  // walk the knots, keep the bin that contains v on the search axis
-  float xl = c.range_min, yl = c.range_min;
-  float bxl = xl, byl = yl, bxr = 0.f, byr = 0.f, rsl = p[2 * K], rsr = p[2 * K + 1];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float xr = k == K - 1 ? c.range_max : xl + fmaf(lw[k], scw, c.min_bin);
-    const float yr = k == K - 1 ? c.range_max : yl + fmaf(lh[k], sch, c.min_bin);
-    if (k == 0) { bxr = xr; byr = yr; }
-    else {
-      const bool hit = v >= (INV ? yl : xl);   // the last bin whose left knot is <= v
-      bxl = hit ? xl : bxl; bxr = hit ? xr : bxr;
-      byl = hit ? yl : byl; byr = hit ? yr : byr;
-      rsl = hit ? p[2 * K + k] : rsl;
-      rsr = hit ? p[2 * K + k + 1] : rsr;
-    }
-    xl = xr; yl = yr;
-  }
-  const float sl = softplus_fast(rsl + c.slope_offset) + c.min_slope;
-  const float sr = softplus_fast(rsr + c.slope_offset) + c.min_slope;
-  const float bw = bxr - bxl, bh = byr - byl;
-  const float rbw = __builtin_amdgcn_rcpf(bw);
-  const float delta = bh * rbw;
-  const float st = sr + sl - 2.f * delta;
-  float res, ldv;
-  if (!INV) {
-    float z = (v - bxl) * rbw;
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
-    res = fmaf(bh * (delta * zz + sl * z1mz), rden, byl);
-    ldv = flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
-  } else {
-    float u = (v - byl) * __builtin_amdgcn_rcpf(bh);
-    u = fminf(fmaxf(u, 0.f), 1.f);
-    const float qc = -delta * u, qb = sl - st * u, qa = delta - qb;
-    float z = -2.f * qc * __builtin_amdgcn_rcpf(qb + __builtin_amdgcn_sqrtf(qb * qb - 4.f * qa * qc));
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    res = fmaf(bw, z, bxl);
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
-    ldv = -flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
-  }
-  if (v <= c.range_min || v >= c.range_max) {  // linear tails
-    const bool below = v <= c.range_min;
-    const float edge = below ? c.range_min : c.range_max;
-    const float s = softplus_fast(p[below ? 2 * K : 3 * K] + c.slope_offset) + c.min_slope;
-    res = INV ? (v - edge) * __builtin_amdgcn_rcpf(s) + edge : (v - edge) * s + edge;
-    ldv = INV ? -flog(s) : flog(s);
-  }
-  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
-  // kernels are built with -fno-honor-nans)
-  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
-  *out = v_nan ? v : res;
-  *logdet = v_nan ? v : ldv;
-}
-
 template <int K, int INV>
 __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, float* __restrict__ ld,
                                                       const float* __restrict__ params, long long rows, int D,
@@ -582,7 +503,6 @@ static bool launch_rqs_rows(float* y, float* ld, const float* params, long long 
 // are added in dim order and written to ldpart[column block][row]; ld_reduce_kernel adds the
 // column blocks in order.
 // ------------------------------------------------------------------------
-constexpr int kCtStride = 129;
 constexpr int kRqsLdsFloats = (kFastLdsFloats > 64 * kCtStride ? kFastLdsFloats : 64 * kCtStride) + 64 * 8;
 
 template <int K, int INV>
@@ -592,11 +512,6 @@ __global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restric
                                                           int Npad, int Kdim, int D, int pass_parity, int gx, int gy,
                                                           RqsConst c) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int P = 3 * K + 1, PPB = 128 / P;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
   int id = blockIdx.x;
   const int nblk = gx * gy;
   if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
@@ -605,49 +520,7 @@ __global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restric
   f32x16 acc[2][2];
   gemm_fast_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);
 
-  const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
-  const int first_t = pass_parity == 0 ? 1 : 0;
-  float* Ct = smem;                       // [64][kCtStride]
-  float* ldl = smem + kRqsLdsFloats - 64 * 8;  // [64][8]
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int col = wn * 64 + u * 32 + i;
-          const float bv = bias[n0 + col];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            Ct[(t * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * kCtStride + col] = acc[t][u][r] + bv;
-        }
-    }
-    __syncthreads();
-    for (int item = tid; item < 64 * PPB; item += 256) {
-      const int r = item & 63, px = item >> 6;
-      const int t_global = nb * PPB + px;
-      const long long row = (long long)m0 + half * 64 + r;
-      float l = 0.f;
-      if (t_global < Dt && row < M) {
-        float* yp = y + row * D + first_t + 2 * t_global;
-        float res;
-        rqs_eval_reg<K, INV>(Ct + r * kCtStride + px * P, c, *yp, &res, &l);
-        *yp = res;
-      }
-      ldl[r * 8 + px] = l;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const long long row = (long long)m0 + half * 64 + tid;
-      if (row < M) {
-        float sum = 0.f;
-#pragma unroll
-        for (int px = 0; px < PPB; ++px) sum += ldl[tid * 8 + px];
-        ldpart[(size_t)nb * M + row] = sum;
-      }
-    }
-    __syncthreads();
-  }
+  rqs_tile_epilogue<K, INV>(acc, bias, n0, m0, nb, M, D, pass_parity, y, ldpart, smem, smem + kRqsLdsFloats - 64 * 8, c);
 }
 
 __global__ __launch_bounds__(256) void ld_reduce_kernel(const float* __restrict__ ldpart, int nblocks, long long rows,
@@ -675,6 +548,13 @@ __global__ __launch_bounds__(256) void k5_layout_kernel(const float* __restrict_
   }
 }
 
+static int launch_ld_reduce(const float* ldpart, int nblocks, int M, float* ld, hipStream_t stream) {
+  hipLaunchKernelGGL(ld_reduce_kernel, dim3((unsigned)std::min<long long>(4096, ((long long)M + 255) / 256)), dim3(256), 0,
+                     stream, ldpart, nblocks, (long long)M, ld);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 template <int K>
 static int launch_gemm_rqs(const float* A, int lda, const float* Wk5, const float* bk5, float* y, float* ldpart,
                            float* ld, int M, int Npad, int Kdim, int D, int par, int inverse, const RqsConst& rc,
@@ -695,10 +575,7 @@ static int launch_gemm_rqs(const float* A, int lda, const float* Wk5, const floa
   else
     hipLaunchKernelGGL((gemm_rqs_kernel<K, 0>), dim3(gx * gy), dim3(256), lds, stream, A, lda, Wk5, bk5, y, ldpart, M,
                        Npad, Kdim, D, par, gx, gy, rc);
-  hipLaunchKernelGGL(ld_reduce_kernel, dim3((unsigned)std::min<long long>(4096, ((long long)M + 255) / 256)), dim3(256), 0,
-                     stream, ldpart, gx, (long long)M, ld);
-  NF_HIP(hipGetLastError());
-  return NF_OK;
+  return launch_ld_reduce(ldpart, gx, M, ld, stream);
 }
 
 // log_prob = base log-density(z) + logdet; optional float64 block sums.
@@ -1008,10 +885,33 @@ int Plan::set_x3(bool on) {
     L.x3_off = total;
     if (L.N >= 64 && L.K >= 32) total += x3_image_halfwords(L.K, L.N);
   }
+  // K5 under the mode: the last Linear of every layer once more, in the K5 column layout
+  const int nlin = desc.num_hidden + 1, P = 3 * desc.rqs_bins + 1, ppb = k5 ? 128 / P : 1;
+  k5_x3_off.assign(desc.num_layers, 0);
+  if (k5)
+    for (int l = 0; l < desc.num_layers; ++l) {
+      k5_x3_off[l] = total;
+      total += x3_image_halfwords(linears[(size_t)l * nlin + nlin - 1].K, k5_npad);
+    }
   if (total == 0) return NF_OK;
   std::vector<unsigned short> img(total);
   for (const Linear& L : linears)
     if (L.N >= 64 && L.K >= 32) pack_w_x3(host_weights.data() + L.w_off, L.K, L.N, img.data() + L.x3_off);
+  if (k5) {
+    std::vector<float> wk;
+    for (int l = 0; l < desc.num_layers; ++l) {
+      const Linear& L = linears[(size_t)l * nlin + nlin - 1];
+      wk.assign((size_t)L.K * k5_npad, 0.f);
+      const float* W = host_weights.data() + L.w_off;
+      for (int col = 0; col < k5_npad; ++col) {  // same map as k5_layout_kernel
+        const int blk = col >> 7, in = col & 127, px = in / P, pq = in % P;
+        const int src = (blk * ppb + px) * P + pq;
+        if (px >= ppb || src >= L.N) continue;
+        for (int k = 0; k < L.K; ++k) wk[(size_t)k * k5_npad + col] = W[(size_t)k * L.N + src];
+      }
+      pack_w_x3(wk.data(), L.K, k5_npad, img.data() + k5_x3_off[l]);
+    }
+  }
   NF_HIP(hipMalloc(&d_wx3, total * sizeof(unsigned short)));
   NF_HIP(hipMemcpy(d_wx3, img.data(), total * sizeof(unsigned short), hipMemcpyHostToDevice));
   return NF_OK;
@@ -1126,12 +1026,17 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       } else
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
-        if (j == nlin - 1 && k5 && !record_tape && !(x3 && d_wx3) && (lda & 3) == 0 &&
+        if (j == nlin - 1 && k5 && !record_tape && (lda & 3) == 0 &&
             (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
           // K5: GEMM + spline in one kernel; theta stays in LDS
           const float* wk = d_wk5 + (size_t)l * k5_layer_floats;
           float* ldpart = d_scratch + ((size_t)2 * act_width + param_width) * scratch_rows;
           int st = NF_ERR_UNSUPPORTED;
+          if (x3 && d_wx3) {
+            st = launch_gemm_x3_rqs(a, lda, d_wx3 + k5_x3_off[l], wk + (size_t)L.K * k5_npad, yc, ldpart, (int)n,
+                                    k5_npad, L.K, D, par, io.inverse_op, rc, stream);
+            if (st == NF_OK) st = launch_ld_reduce(ldpart, k5_npad / 128, (int)n, ldc, stream);
+          } else
           switch (rc.K) {
             case 6: st = launch_gemm_rqs<6>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;
             case 8: st = launch_gemm_rqs<8>(a, lda, wk, wk + (size_t)L.K * k5_npad, yc, ldpart, ldc, (int)n, k5_npad, L.K, D, par, io.inverse_op, rc, stream); break;

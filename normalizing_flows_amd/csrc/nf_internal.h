@@ -227,6 +227,7 @@ struct Plan {
   float* d_wk5 = nullptr;            // per layer: [Kdim][k5_npad] then the bias [k5_npad]
   size_t k5_layer_floats = 0;
   int k5_npad = 0;
+  std::vector<size_t> k5_x3_off;     // per layer: the K5-layout split image inside d_wx3 (bf16x3 mode)
   int refresh_k5(hipStream_t stream);  // from d_weights (after build and after every optimiser step)
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
@@ -249,6 +250,9 @@ int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const 
 size_t x3_image_halfwords(int K, int N);
 void pack_w_x3(const float* W /*[K][N]*/, int K, int N, unsigned short* image);
 bool gemm_x3_applicable(const float* A, int lda, int N, int K);
+int launch_gemm_x3_rqs(const float* A, int lda, const unsigned short* wimg, const float* bias, float* y,
+                       float* ldpart, int M, int Npad, int K, int D, int par, int inverse, const RqsConst& rc,
+                       hipStream_t stream);
 int launch_gemm_x3(const float* A, int lda, const unsigned short* wimg, const float* bias, float* Cm, int ldc,
                    int M, int N, int K, int act, hipStream_t stream);
 int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,

@@ -577,6 +577,48 @@ def test_rqs_general_path_register_kernel(nfa, monkeypatch, K, D, hidden, L, row
     assert_close(ldb, ldr, "general rqs inverse logdet", FLOOR * np.abs(l32 - ldr).max())
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("K,D,hidden,L,rows,parity,std", [(6, 10, (128,), 2, 777, 1, 0.08), (8, 7, (96, 72), 3, 130, 0, 0.08),
+                                                          (10, 31, (128, 128), 2, 515, 1, 0.08),
+                                                          (12, 30, (64, 96), 2, 129, 0, 0.08),
+                                                          (8, 64, (256,), 2, 1, 1, 0.01), (8, 64, (256,), 3, 3, 0, 0.01)])
+def test_rqs_spline_in_gemm_epilogue(nfa, monkeypatch, mode, K, D, hidden, L, rows, parity, std):
+    """SURVEY's K5: spline layers whose last Linear runs on the 128-wide MFMA GEMM apply the spline in that
+    GEMM's epilogue (gemm_rqs_kernel / gemm_x3_rqs_kernel), K in {6, 8, 10, 12}: odd and even D, both mask
+    parities, ragged row counts, both walks, both matmul modes -- against the oracle and against the same
+    flow with the fusion switched off (NF_NO_K5: GEMM, parameter tensor in HBM, transform kernel).
+    (`std` of the last Linear is small for the 64-D / 256-wide cases: at 0.08 that flow's inverse is
+    ill-conditioned -- float32 NumPy, the unfused path and this kernel all land 3 units away from float64.)"""
+    from normalizing_flows_amd import _lib
+    spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=-5.0, range_max=5.0,
+                           final_std=std, first_parity=parity)
+    x = (np.random.default_rng(K * 100 + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
+    x[0, 0] = 7.5       # linear tail
+    x[-1, D - 1] = -5.0  # range edge
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    f = rqs_flow(nfa, spec, parity)
+    f.set_option("hidden_matmul", mode)
+    assert f.kernel_name == "generic_gemm"
+    got = f.log_prob(x)
+    assert_close(got, ref, "K5 log_prob", FLOOR * e32)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    z32, l32 = O.chain_forward(spec, x, np.float32)
+    assert_close(z, zr, "K5 forward", FLOOR * np.abs(z32 - zr).max())
+    assert_close(ld, ldr, "K5 forward logdet", FLOOR * np.abs(l32 - ldr).max())
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr = O.chain_inverse(spec, z)
+    x32, l32 = O.chain_inverse(spec, z, np.float32)
+    assert_close(xb, xr, "K5 inverse", FLOOR * np.abs(x32 - xr).max())
+    assert_close(ldb, ldr, "K5 inverse logdet", FLOOR * np.abs(l32 - ldr).max())
+    monkeypatch.setenv("NF_NO_K5", "1")
+    g = rqs_flow(nfa, spec, parity)
+    g.set_option("hidden_matmul", mode)
+    plain = g.log_prob(x)
+    assert np.abs(plain.astype(np.float64) - got).max() <= 2 * max(FLOOR * e32, float(tol(ref).max()))
+
+
 # ------------------------------------------------------------------ backward pass / training step
 def _flat(layers):
     return np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()])
