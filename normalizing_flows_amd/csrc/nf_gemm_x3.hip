@@ -9,15 +9,20 @@
 // lane's accumulator registers hold 32 consecutive output units of one sample row: coalesced
 // float32 stores, as in gemm_fast_kernel.
 //   * W is split and laid out ONCE on the host (pack_w_x3): per (128-column block, 32-deep k
-//     tile) one contiguous 24 KiB image [part 3][k16 2][column tile 4][lane 64][8 bf16] that is
-//     copied to LDS verbatim and read back with one ds_read_b128 per operand.
+//     tile) one contiguous 24 KiB image [part 3][k16 2][column tile 4][lane 64][8 bf16]: the B-operand
+//     order, read by each wave straight into registers (1 KiB per instruction, L2-resident), never
+//     through LDS.
 //   * A stays float32 row-major in HBM (it is the previous Linear's output, or the sample
-//     matrix).  Each thread loads 2 x 8 consecutive k of one row (4 x float4; a row's 128-byte
-//     line is shared by two lanes), splits them in registers (11 VALU per pair of values, hidden behind the
-//     MFMAs of the other workgroup on the CU) and writes [part][k16][row 128][16 bf16] to LDS --
-//     with a 16-deep k step the row-major bf16 tile IS the A operand order.
-// 128x128 block tile, BK = 32, 4 waves of 64x64, one 48 KiB LDS stage + the next tile in
-// registers, three workgroups per CU (144 KiB of LDS, <= 168 registers).
+//     matrix).  Each thread loads 4 consecutive k of four rows (8 lanes cover a row's 128-byte line, a
+//     wave's instruction 8 whole lines), splits them in registers (11 VALU per pair of values) and writes
+//     [part][k16][row 128][16 bf16] to LDS -- with a 16-deep k step the row-major bf16 tile IS the A
+//     operand order.
+// 128x128 block tile, BK = 32, 4 waves of 64x64, two 24 KiB LDS stages of A (one barrier per k tile),
+// two workgroups per CU (176 registers).  What was measured on the way (profiles/microbench/
+// gemm_x3_probe.hip, gemm_x3_wide_probe.hip): W through LDS, W direct, 128x256 blocks with
+// 128x64 wave tiles (half the vector-memory bytes and split work per MFMA), branch-free prefetch and the
+// split interleaved with the MFMAs all land within 4 % of each other -- the MFMA stream itself runs at
+// 71 % of its nominal rate on dense operands (88 % on zeros: clock/power), and that is what binds.
 #include "nf_bf16x3.h"
 #include "nf_internal.h"
 #include "nf_rqs_eval.h"
@@ -64,57 +69,101 @@ void pack_w_x3(const float* W, int K, int N, unsigned short* img) {
 // ---- device ----------------------------------------------------------------------------------
 // The k loop shared by gemm_x3_kernel and gemm_x3_rqs_kernel: acc[t][u] = the wave's 2 x 2 tiles of
 // A[m0.., :] @ W[:, 128 nb ..]; returns after a barrier (LDS free).
+//   * W never touches LDS: the host image is already in B-operand order, so a wave reads its two column
+//     tiles' fragments (1 KiB per instruction, L2-resident: a column block's images are shared by every
+//     row block) straight into registers, one 16-deep k step ahead of their use.
+//   * A goes through LDS (split on the fly, see the file header) in two stages: one barrier per k tile.
 __device__ __forceinline__ void gemm_x3_mainloop(const float* __restrict__ A, int lda, const uint4* __restrict__ Wimg,
                                                  int M, int K, int m0, int nb, uint4* lds_u4, f32x16 (&acc)[2][2]) {
-  uint4* As = lds_u4;             // [part 3][k16 2][row 128][2]   (2 uint4 = 16 bf16 per row)
-  uint4* Ws = lds_u4 + kTileU4;   // [part 3][k16 2][ntile 4][lane 64]
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = (K + XBK - 1) / XBK;
 
-  // this thread's share of an A tile: row arow, k = 16 ks + 8 akq + 0..7 for ks = 0, 1 -- so that the
-  // 64 lanes of one ds_write_b128 cover one contiguous KiB of the [k16][row][16] plane
-  const int arow = tid >> 1, akq = tid & 1;
-  const float* arow_ptr = A + (size_t)(m0 + arow) * lda;
-  const bool arow_ok = m0 + arow < M;
-  const uint4* wsrc = Wimg + (size_t)nb * nk * kTileU4 + tid;
+  // this thread's share of an A tile: rows (tid >> 3) + 32 e, e = 0..3, the 16-byte chunk c = tid & 7 of the
+  // row's 128-byte line (k = 4c .. 4c+3 of the tile): a wave's load instruction covers 8 whole lines
+  const int c = tid & 7, ar0 = tid >> 3;
+  const uint4* wsrc = Wimg + (size_t)nb * nk * kTileU4 + wn * 128 + lane;  // + kt*kTileU4 + ((p*2+ks)*4 + t)*64
 
-  // the next tile, held in named registers (arrays captured by a lambda end up in scratch)
   float4 ra0, ra1, ra2, ra3;
-  uint4 rw0, rw1, rw2, rw3, rw4, rw5;
-#define NF_A_LOAD(e_, dst_)                                                                             \
-  {                                                                                                     \
-    const int gk_ = kt_ * XBK + ((e_) >> 1) * 16 + akq * 8 + ((e_) & 1) * 4;                            \
-    dst_ = (arow_ok && gk_ < K) ? *reinterpret_cast<const float4*>(arow_ptr + gk_) : make_float4(0.f, 0.f, 0.f, 0.f); \
-  }
+  // Loads carry no branch and no select: rows past M and the prefetch past the last tile are clamped to
+  // valid addresses, and a k tail re-reads the row's own last chunk -- the image's rows k >= K are zero.
+  // (A predicated load is a branch; at its join the compiler has to assume the shorter queue and waits
+  // for EVERY outstanding load, and the prefetch distance collapses to zero.)
+  const float* arow0 = A + (size_t)min(m0 + ar0, M - 1) * lda + c * 4;
+  const float* arow1 = A + (size_t)min(m0 + ar0 + 32, M - 1) * lda + c * 4;
+  const float* arow2 = A + (size_t)min(m0 + ar0 + 64, M - 1) * lda + c * 4;
+  const float* arow3 = A + (size_t)min(m0 + ar0 + 96, M - 1) * lda + c * 4;
+  const int klast = (K - 4) - c * 4;  // the last float4 of a row this thread may start at, minus its chunk
+#define NF_A_LOAD(ptr_, dst_) dst_ = *reinterpret_cast<const float4*>(ptr_ + min(kt_ * XBK, klast));
 #define NF_FETCH(kt_expr)                                   \
   {                                                         \
     const int kt_ = (kt_expr);                              \
-    NF_A_LOAD(0, ra0) NF_A_LOAD(1, ra1) NF_A_LOAD(2, ra2) NF_A_LOAD(3, ra3) \
-    const uint4* w_ = wsrc + (size_t)kt_ * kTileU4;         \
-    rw0 = w_[0]; rw1 = w_[256]; rw2 = w_[512]; rw3 = w_[768]; rw4 = w_[1024]; rw5 = w_[1280]; \
+    NF_A_LOAD(arow0, ra0) NF_A_LOAD(arow1, ra1) NF_A_LOAD(arow2, ra2) NF_A_LOAD(arow3, ra3) \
   }
-#define NF_SPLIT4(r_, q_)                                          \
-  split_pair(r_.x, r_.y, hi##q_##a, mid##q_##a, lo##q_##a);        \
-  split_pair(r_.z, r_.w, hi##q_##b, mid##q_##b, lo##q_##b);
-#define NF_STASH()                                                                  \
+  // LDS A tile: [part 3][k16 2][row 128][16 bf16]; this thread's four values of a row are 8 bytes of it
+#define NF_STASH1(r_, e_)                                                           \
   {                                                                                 \
-    unsigned hi0a, hi0b, hi1a, hi1b, hi2a, hi2b, hi3a, hi3b;                        \
-    unsigned mid0a, mid0b, mid1a, mid1b, mid2a, mid2b, mid3a, mid3b;                \
-    unsigned lo0a, lo0b, lo1a, lo1b, lo2a, lo2b, lo3a, lo3b;                        \
-    NF_SPLIT4(ra0, 0) NF_SPLIT4(ra1, 1) NF_SPLIT4(ra2, 2) NF_SPLIT4(ra3, 3)         \
-    uint4* dst_ = As + tid; /* = (row * 2 + akq) of k16 step 0; step 1 is 256 further */ \
-    dst_[0] = make_uint4(hi0a, hi0b, hi1a, hi1b);                                   \
-    dst_[256] = make_uint4(hi2a, hi2b, hi3a, hi3b);                                 \
-    dst_[512] = make_uint4(mid0a, mid0b, mid1a, mid1b);                             \
-    dst_[768] = make_uint4(mid2a, mid2b, mid3a, mid3b);                             \
-    dst_[1024] = make_uint4(lo0a, lo0b, lo1a, lo1b);                                \
-    dst_[1280] = make_uint4(lo2a, lo2b, lo3a, lo3b);                                \
-    Ws[tid] = rw0; Ws[tid + 256] = rw1; Ws[tid + 512] = rw2;                        \
-    Ws[tid + 768] = rw3; Ws[tid + 1024] = rw4; Ws[tid + 1280] = rw5;                \
+    unsigned h0_, m0_, l0_, h1_, m1_, l1_;                                          \
+    split_pair(r_.x, r_.y, h0_, m0_, l0_);                                          \
+    split_pair(r_.z, r_.w, h1_, m1_, l1_);                                          \
+    uint2* d_ = sbase_ + (size_t)(32 * (e_)) * 4;                                   \
+    d_[0] = make_uint2(h0_, h1_);                                                   \
+    d_[2 * 128 * 4] = make_uint2(m0_, m1_);                                         \
+    d_[4 * 128 * 4] = make_uint2(l0_, l1_);                                         \
+  }
+#define NF_STASH(stage_)                                                            \
+  {                                                                                 \
+    uint2* sbase_ = reinterpret_cast<uint2*>(lds_u4 + (stage_) * kTileU4) + ((size_t)((c >> 2) * 128 + ar0) * 4 + (c & 3)); \
+    NF_STASH1(ra0, 0) NF_STASH1(ra1, 1) NF_STASH1(ra2, 2) NF_STASH1(ra3, 3)         \
+  }
+#define NF_B_LOAD(dst_, kt_, ks_)                                                   \
+  {                                                                                 \
+    const uint4* w_ = wsrc + (size_t)(kt_) * kTileU4 + (ks_) * 256;                 \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) dst_[t_][p_] = w_[p_ * 512 + t_ * 64]; \
+  }
+#define NF_A_FRAGS(stage_, ks_)                                                     \
+    const uint4* As_ = lds_u4 + (stage_) * kTileU4;                                 \
+    bf16x8 Af[2][3];                                                                \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                              \
+        Af[t_][p_] = __builtin_bit_cast(bf16x8, As_[(((p_ * 2 + (ks_)) * 128) + wm * 64 + t_ * 32 + i) * 2 + h]);
+#define NF_STEP(stage_, ks_, B_)                                                    \
+  {                                                                                 \
+    NF_A_FRAGS(stage_, ks_)                                                         \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                \
+      _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                              \
+        bf16x3::mfma6(acc[t_][u_], Af[t_][0], Af[t_][1], Af[t_][2], __builtin_bit_cast(bf16x8, B_[u_][0]), \
+                      __builtin_bit_cast(bf16x8, B_[u_][1]), __builtin_bit_cast(bf16x8, B_[u_][2])); \
+  }
+  // the same step with the split of the next A tile spread over its MFMAs: per (t, u) six MFMAs and one
+  // register's share of the split (two split_pair, three ds_write_b64), fenced so that the compiler keeps
+  // the mix (a bf16 MFMA leaves the vector issue free for ~6 VALU instructions)
+#define NF_STEP_STASH1(B_, t_, u_, r_, e_)                                              \
+    bf16x3::mfma6(acc[t_][u_], Af[t_][0], Af[t_][1], Af[t_][2], __builtin_bit_cast(bf16x8, B_[u_][0]), \
+                  __builtin_bit_cast(bf16x8, B_[u_][1]), __builtin_bit_cast(bf16x8, B_[u_][2])); \
+    NF_STASH1(r_, e_)                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+    __builtin_amdgcn_sched_barrier(0);
+#define NF_STEP_STASH(stage_, ks_, B_, next_stage_)                                 \
+  {                                                                                 \
+    NF_A_FRAGS(stage_, ks_)                                                         \
+    uint2* sbase_ = reinterpret_cast<uint2*>(lds_u4 + (next_stage_) * kTileU4) + ((size_t)((c >> 2) * 128 + ar0) * 4 + (c & 3)); \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    NF_STEP_STASH1(B_, 0, 0, ra0, 0) NF_STEP_STASH1(B_, 0, 1, ra1, 1) NF_STEP_STASH1(B_, 1, 0, ra2, 2) NF_STEP_STASH1(B_, 1, 1, ra3, 3) \
   }
 
 #pragma unroll
@@ -124,40 +173,35 @@ __device__ __forceinline__ void gemm_x3_mainloop(const float* __restrict__ A, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  uint4 b0[2][3], b1[2][3];  // the B fragments of k16 step 0 / 1 of a tile
+  NF_B_LOAD(b0, 0, 0);
   NF_FETCH(0);
-  NF_STASH();
+  NF_STASH(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) NF_FETCH(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 Af[2][3], Bf[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          Af[t][p] = __builtin_bit_cast(bf16x8, As[(((p * 2 + ks) * 128) + wm * 64 + t * 32 + i) * 2 + h]);
-          Bf[t][p] = __builtin_bit_cast(bf16x8, Ws[((p * 2 + ks) * 4 + wn * 2 + t) * 64 + lane]);
-        }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          bf16x3::mfma6(acc[t][u], Af[t][0], Af[t][1], Af[t][2], Bf[u][0], Bf[u][1], Bf[u][2]);
-    }
+    const int cur = kt & 1;
+    const int nxt = min(kt + 1, nk - 1);  // the last iteration re-loads and re-stashes its own tile (unused)
+    NF_FETCH(nxt);
+    NF_B_LOAD(b1, kt, 1);
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay ahead of the step that hides them
+    NF_STEP(cur, 0, b0);
+    NF_B_LOAD(b0, nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    NF_STEP_STASH(cur, 1, b1, cur ^ 1);
     __syncthreads();
-    if (kt + 1 < nk) {
-      NF_STASH();
-      __syncthreads();
-    }
   }
 #undef NF_A_LOAD
 #undef NF_FETCH
-#undef NF_SPLIT4
+#undef NF_STASH1
 #undef NF_STASH
+#undef NF_B_LOAD
+#undef NF_STEP
+#undef NF_A_FRAGS
+#undef NF_STEP_STASH1
+#undef NF_STEP_STASH
 }
 
-__global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict__ A, int lda,
                                                          const uint4* __restrict__ Wimg,
                                                          const float* __restrict__ bias, float* __restrict__ Cm,
                                                          int ldc, int M, int N, int K, int act, int gx, int gy) {
@@ -196,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
 // SURVEY's K5 under the mode: the last Linear of a spline layer (weights in Plan's K5 column layout,
 // split image) with the spline in the epilogue (rqs_tile_epilogue, nf_rqs_eval.h).
 template <int KB, int INV>
-__global__ __launch_bounds__(256, 3) void gemm_x3_rqs_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 2) void gemm_x3_rqs_kernel(const float* __restrict__ A, int lda,
                                                              const uint4* __restrict__ Wimg,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              float* __restrict__ ldpart, int M, int K, int D,

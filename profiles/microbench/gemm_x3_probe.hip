@@ -1,0 +1,204 @@
+// Where does gemm_x3_kernel (nf_gemm_x3.hip) lose its time?  The main loop of the kernel (B fragments straight
+// from the L2-resident image, A split on the fly into a two-stage LDS tile) with single ingredients switched off,
+// on the MNIST-shape last Linear (M = 65536, K = 512, N = 10112), dense random operands.  Bits of V:
+//   1  no global loads of A (constant registers are split and stashed)
+//   2  no split (the raw words are stashed)
+//   4  no global loads of B (fragments loaded once)
+//   8  no ds_read of A (fragments read once)
+//   16 no ds_write / barrier at all
+//   32 no MFMAs
+//   64 A loaded as whole 128-byte lines (8 lanes per row, ds_write_b64) instead of two lanes per row
+// build: hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize -I ../../normalizing_flows_amd/csrc
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "nf_bf16x3.h"
+using nf::bf16x3::bf16x8;
+using nf::bf16x3::f32x16;
+using nf::bf16x3::split_pair;
+constexpr int XBM = 128, XBN = 128, XBK = 32, kTileU4 = 1536;
+
+template <int V, int OCC>
+__global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ A, int lda, const uint4* __restrict__ Wimg,
+                                                float* __restrict__ Cm, int ldc, int M, int N, int K, int gx, int gy) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int nblk = gx * gy;
+  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+  const int mb = id / gx, nb = id % gx, m0 = mb * XBM, n0 = nb * XBN;
+  const int nk = K / XBK;
+  const int arow = tid >> 1, akq = tid & 1;
+  const float* arow_ptr = A + (size_t)(m0 + arow) * lda + akq * 8;
+  const uint4* wsrc = Wimg + (size_t)nb * nk * kTileU4 + wn * 128 + lane;
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 ra[4];
+  uint4 b0[2][3], b1[2][3];
+  bf16x8 Af[2][3];
+  // line pattern: lane -> row (tid >> 3) + 32 e, 16-byte chunk (tid & 7) of the row's 128-byte line
+  const float* aline_ptr = A + (size_t)(m0 + (tid >> 3)) * lda + (tid & 7) * 4;
+  auto fetch = [&](int kt) {
+    if (V & 64) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(aline_ptr + (size_t)(32 * e) * lda + kt * XBK);
+      return;
+    }
+    if (V & 1) { if (kt == 0) for (int e = 0; e < 4; ++e) ra[e] = make_float4(tid * 1e-3f, e + 0.37f, kt + 1.11f, 0.77f); return; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ra[e] = *reinterpret_cast<const float4*>(arow_ptr + kt * XBK + (e >> 1) * 16 + (e & 1) * 4);
+  };
+  auto stash = [&](int stage) {
+    if (V & 16) return;
+    if (V & 64) {
+      const int c = tid & 7, ks = c >> 2;
+      uint2* base = reinterpret_cast<uint2*>(lds_u4 + stage * kTileU4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split_pair(ra[e].x, ra[e].y, h0, m0_, l0);
+        split_pair(ra[e].z, ra[e].w, h1, m1, l1);
+        const int row = (tid >> 3) + 32 * e;
+        uint2* d = base + ((size_t)(ks * 128 + row) * 4 + (c & 3));  // [part][ks][row][4 x 8 bytes]
+        d[0] = make_uint2(h0, h1);
+        d[2 * 128 * 4] = make_uint2(m0_, m1);
+        d[4 * 128 * 4] = make_uint2(l0, l1);
+      }
+      return;
+    }
+    unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (V & 2) {
+        hi[2 * e] = __float_as_uint(ra[e].x); hi[2 * e + 1] = __float_as_uint(ra[e].y);
+        mid[2 * e] = __float_as_uint(ra[e].z); mid[2 * e + 1] = __float_as_uint(ra[e].w);
+        lo[2 * e] = hi[2 * e] ^ 0x55u; lo[2 * e + 1] = mid[2 * e] ^ 0x33u;
+      } else {
+        split_pair(ra[e].x, ra[e].y, hi[2 * e], mid[2 * e], lo[2 * e]);
+        split_pair(ra[e].z, ra[e].w, hi[2 * e + 1], mid[2 * e + 1], lo[2 * e + 1]);
+      }
+    }
+    uint4* dst = lds_u4 + stage * kTileU4 + tid;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);     dst[256] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    dst[512] = make_uint4(mid[0], mid[1], mid[2], mid[3]); dst[768] = make_uint4(mid[4], mid[5], mid[6], mid[7]);
+    dst[1024] = make_uint4(lo[0], lo[1], lo[2], lo[3]);   dst[1280] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+  };
+  auto bload = [&](uint4 (&dst)[2][3], int kt, int ks) {
+    if ((V & 4) && (kt | ks)) return;
+    const uint4* w = wsrc + (size_t)kt * kTileU4 + ks * 256;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dst[t][p] = w[p * 512 + t * 64];
+  };
+  auto step = [&](int stage, int ks, uint4 (&B)[2][3], bool first) {
+    const uint4* As = lds_u4 + stage * kTileU4;
+    if (!(V & 8) || first)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          Af[t][p] = __builtin_bit_cast(bf16x8, As[(((p * 2 + ks) * 128) + wm * 64 + t * 32 + i) * 2 + h]);
+    if (V & 32) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u][0] += Af[t][0][0] * 1.f + __uint_as_float(B[u][0].x) + __uint_as_float(B[u][1].y) + __uint_as_float(B[u][2].z) + (float)Af[t][1][1] + (float)Af[t][2][2];
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        nf::bf16x3::mfma6(acc[t][u], Af[t][0], Af[t][1], Af[t][2], __builtin_bit_cast(bf16x8, B[u][0]),
+                          __builtin_bit_cast(bf16x8, B[u][1]), __builtin_bit_cast(bf16x8, B[u][2]));
+  };
+  bload(b0, 0, 0);
+  if (V & 4) bload(b1, 0, 0);
+  fetch(0);
+  stash(0);
+  if (V & 16) { for (int q = tid; q < 2 * kTileU4; q += 256) lds_u4[q] = make_uint4(q, q * 3, q * 5, q * 7); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) fetch(kt + 1);
+    bload(b1, kt, 1);
+    step(cur, 0, b0, kt == 0);
+    if (more) bload(b0, kt + 1, 0);
+    step(cur, 1, b1, false);
+    if (more) stash(cur ^ 1);
+    if (!(V & 16)) __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        Cm[(size_t)row * ldc + col] = acc[t][u][r];
+      }
+    }
+}
+
+template <int V, int OCC>
+static void run(const char* what, const float* A, const uint4* W, float* C, int M, int N, int K) {
+  const int gx = N / XBN, gy = M / XBM;
+  const size_t lds = 2 * kTileU4 * sizeof(uint4);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<V, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe<V, OCC>), dim3(gx * gy), dim3(256), lds, 0, A, K, W, C, N, M, N, K, gx, gy);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep) best = ms < best ? ms : best;
+  }
+  const double mfma = (double)M / 32 * N / 32 * K / 16 * 6;
+  printf("V=%2d occ=%d %-44s %7.3f ms   %6.1f %% of the bf16 MFMA issue rate at 2.4 GHz  (%s)\n", V, OCC, what, best,
+         100.0 * mfma * 32 / 1024 / 2.4e9 / (best * 1e-3), hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+  const int M = 65536, K = 512, N = 10112;
+  float* A; uint4* W; float* C;
+  hipMalloc(&A, (size_t)M * K * 4);
+  hipMalloc(&W, (size_t)(N / XBN) * (K / XBK) * kTileU4 * 16);
+  hipMalloc(&C, (size_t)M * N * 4);
+  std::vector<float> ha((size_t)M * K);
+  unsigned s = 12345u;
+  for (auto& v : ha) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 16777216.0f) - 0.3f) * 1.7f; }
+  const bool zeros = getenv("PROBE_ZEROS") != nullptr;  // all-zero operands: same instruction stream, least switching power
+  if (zeros) for (auto& v : ha) v = 0.f;
+  hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
+  std::vector<unsigned short> hw((size_t)(N / XBN) * (K / XBK) * kTileU4 * 8);
+  for (size_t q = 0; q < hw.size(); ++q) {  // plausible hi/mid/lo magnitudes
+    s = s * 1664525u + 1013904223u;
+    const int part = (int)((q / 8 / 512) % 3);
+    const float v = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f) * (part == 0 ? 0.1f : part == 1 ? 4e-4f : 1.5e-6f);
+    hw[q] = nf::bf16x3::host_bf16_rne(v);
+  }
+  if (zeros) for (auto& v : hw) v = 0;
+  hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  run<0, 3>("full", A, W, C, M, N, K);
+  run<0, 2>("full, 2 workgroups per CU", A, W, C, M, N, K);
+  run<64, 3>("A as whole lines", A, W, C, M, N, K);
+  run<64, 2>("A as whole lines, 2 workgroups per CU", A, W, C, M, N, K);
+  run<1, 3>("no A global loads", A, W, C, M, N, K);
+  run<2, 3>("no split", A, W, C, M, N, K);
+  run<3, 3>("no A loads, no split", A, W, C, M, N, K);
+  run<4, 3>("no B loads", A, W, C, M, N, K);
+  run<8, 3>("no ds_read", A, W, C, M, N, K);
+  run<16 + 1, 3>("no A staging at all (no loads/split/ds_write/barrier)", A, W, C, M, N, K);
+  run<16 + 1 + 4, 3>("ds_read + MFMA only", A, W, C, M, N, K);
+  run<16 + 1 + 4 + 8, 3>("MFMA only", A, W, C, M, N, K);
+  run<32, 3>("everything but the MFMAs", A, W, C, M, N, K);
+  return 0;
+}
