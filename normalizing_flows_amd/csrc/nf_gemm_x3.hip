@@ -210,10 +210,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // one XCD sees a contiguous run of tiles
-  const int mb = id / gx, nb = id % gx;
+  int mb, nb;
+  block_to_tile(blockIdx.x, gx, gy, mb, nb);
   const int m0 = mb * XBM, n0 = nb * XBN;
   f32x16 acc[2][2];
   gemm_x3_mainloop(A, lda, Wimg, M, K, m0, nb, lds_u4, acc);
@@ -246,10 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_rqs_kernel(const float* __rest
                                                              float* __restrict__ ldpart, int M, int K, int D,
                                                              int pass_parity, int gx, int gy, RqsConst c) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int mb = id / gx, nb = id % gx;
+  int mb, nb;
+  block_to_tile(blockIdx.x, gx, gy, mb, nb);
   const int m0 = mb * XBM, n0 = nb * XBN;
   f32x16 acc[2][2];
   gemm_x3_mainloop(A, lda, Wimg, M, K, m0, nb, lds_u4, acc);

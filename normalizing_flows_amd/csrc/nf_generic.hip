@@ -212,10 +212,9 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int m0 = (id / gx) * FBM, n0 = (id % gx) * FBN;
+  int mb, nb;
+  block_to_tile(blockIdx.x, gx, gy, mb, nb);
+  const int m0 = mb * FBM, n0 = nb * FBN;
   f32x16 acc[2][2];
   gemm_fast_mainloop(A, lda, W, M, N, K, m0, n0, smem, acc);
 
@@ -512,10 +511,8 @@ __global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restric
                                                           int Npad, int Kdim, int D, int pass_parity, int gx, int gy,
                                                           RqsConst c) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int mb = id / gx, nb = id % gx;
+  int mb, nb;
+  block_to_tile(blockIdx.x, gx, gy, mb, nb);
   const int m0 = mb * FBM, n0 = nb * FBN;
   f32x16 acc[2][2];
   gemm_fast_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);

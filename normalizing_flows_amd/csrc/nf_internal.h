@@ -243,6 +243,26 @@ struct Plan {
   // y [rows, D] and ld [rows] hold the chain's input state and are updated in place
   int walk(float* y, float* ld, const ChainIO& io, hipStream_t stream);
 };
+// Which 128 x 128 tile a GEMM workgroup takes (gx column blocks x gy row blocks, one workgroup each).
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2, so (i) every XCD gets one
+// contiguous run of the tile sequence and (ii) the sequence walks bands of kTileBand row blocks column by
+// column: the ~64 workgroups resident on an XCD then cover an 8 x 8 patch -- the band's A rows (8 x 256 KiB
+// at K = 512) stay in L2 and a column block's weights are fetched once per band, not once per row block.
+// (Row-major order streamed the whole 20-30 MB weight image of the MNIST-shape last Linear through every
+// XCD for every row block: 11-17 GB of fabric reads per launch against 0.5 GB algorithmic, rocprofv3
+// FETCH_SIZE)
+constexpr int kTileBand = 8;
+__device__ __forceinline__ void block_to_tile(int id, int gx, int gy, int& mb, int& nb) {
+  const int nblk = gx * gy;
+  const int base = nblk >> 3, rem = nblk & 7, x = id & 7;
+  id = x * base + (x < rem ? x : rem) + (id >> 3);
+  const int band = id / (kTileBand * gx);
+  const int rows = gy - band * kTileBand < kTileBand ? gy - band * kTileBand : kTileBand;
+  const int r = id - band * kTileBand * gx;
+  nb = r / rows;
+  mb = band * kTileBand + r - nb * rows;
+}
+
 // nf_mlp_small.hip: a whole conditioner (every Linear K, N <= 64) in one launch
 bool mlp_small_applicable(const Linear* Ls, int nlin);
 int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights, int act,

@@ -4,7 +4,7 @@
 # Kernel trace + stats, then separate --pmc passes; summaries land in profiles/r01/config_<c|d>_*.
 set -e
 export TMPDIR=/tmp
-for cfg in c d; do
+for cfg in ${@:-c d}; do
   OUT=gpurun_out/prof_cfg_$cfg
   mkdir -p $OUT
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -- python3 profiles/bench_configs.py $cfg > $OUT/kt.log 2>&1
