@@ -919,6 +919,7 @@ void Plan::release() {
   if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
   k5 = false;
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
+  hipFree(bwd.d_small_partials);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
   bwd = Backward();
   if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }

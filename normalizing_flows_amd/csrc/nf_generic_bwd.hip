@@ -279,20 +279,38 @@ __device__ float rqs_bwd_one(const float* __restrict__ p, float* __restrict__ gp
   return gx;
 }
 
+// One (row, transformed dim) item per thread and pass.  An item's 3K+1 parameters are contiguous, a thread
+// reading its own would touch 64 different cache lines per instruction: the workgroup's 256 items' parameters
+// (one contiguous block) go through LDS with coalesced loads, the gradient goes back the same way (a lane's
+// values are then a stride-(3K+1) LDS access: odd stride, conflict-free).
 template <int KMAX>
 __global__ __launch_bounds__(256) void rqs_masked_bwd_kernel(const float* __restrict__ v, float* __restrict__ G,
                                                              const float* __restrict__ th, float* __restrict__ dth,
                                                              long long rows, int D, int pass_parity, float gld,
                                                              RqsConst c) {
+  extern __shared__ __attribute__((aligned(16))) float sm_bwd[];
   const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
   const int P = 3 * c.K + 1;
   const long long total = rows * Dt;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-    const long long r = q / Dt;
-    const int t = (int)(q % Dt);
-    const int d = 2 * t + (pass_parity == 0 ? 1 : 0);
-    const size_t po = (size_t)r * Dt * P + (size_t)t * P;
-    G[r * D + d] = rqs_bwd_one<KMAX>(th + po, dth + po, c, v[r * D + d], G[r * D + d], gld);
+  float* sp = sm_bwd;             // [256][P] parameters
+  float* sg = sm_bwd + 256 * P;   // [256][P] their gradient
+  for (long long q0 = (long long)blockIdx.x * 256; q0 < total; q0 += (long long)gridDim.x * 256) {
+    const int items = (int)(total - q0 < 256 ? total - q0 : 256);
+    const int nfl = items * P;
+    const float* src = th + (size_t)q0 * P;
+    for (int e = threadIdx.x; e < nfl; e += 256) sp[e] = src[e];
+    __syncthreads();
+    if ((int)threadIdx.x < items) {
+      const long long q = q0 + threadIdx.x;
+      const long long r = q / Dt;
+      const int t = (int)(q - r * Dt);
+      const int d = 2 * t + (pass_parity == 0 ? 1 : 0);
+      G[r * D + d] = rqs_bwd_one<KMAX>(sp + threadIdx.x * P, sg + threadIdx.x * P, c, v[r * D + d], G[r * D + d], gld);
+    }
+    __syncthreads();
+    float* dst = dth + (size_t)q0 * P;
+    for (int e = threadIdx.x; e < nfl; e += 256) dst[e] = sg[e];
+    __syncthreads();
   }
 }
 
@@ -412,7 +430,8 @@ int Plan::prepare_backward() {
     return NF_ERR_UNSUPPORTED;
   }
   hipFree(b.d_grad); hipFree(b.d_wT); hipFree(b.d_canon_index); hipFree(b.d_zero); hipFree(b.d_partials);
-  b.d_grad = b.d_wT = b.d_zero = b.d_partials = nullptr;
+  hipFree(b.d_small_partials);
+  b.d_grad = b.d_wT = b.d_zero = b.d_partials = b.d_small_partials = nullptr;
   b.d_canon_index = nullptr;
   b.ready = false;
   b.n_weights = host_weights.size();
@@ -434,6 +453,18 @@ int Plan::prepare_backward() {
   // up to 256 row-chunk slabs of the largest Linear, at most 512 MiB
   b.partial_floats = std::max(biggest, std::min<size_t>(biggest * 256, ((size_t)512 << 20) / sizeof(float)));
   NF_HIP(hipMalloc(&b.d_partials, b.partial_floats * sizeof(float)));
+  {  // narrow conditioners: one slab of a layer's weight span per workgroup
+    const int nlin = desc.num_hidden + 1;
+    size_t span = 0;
+    bool any = false;
+    for (int l = 0; l < desc.num_layers; ++l) {
+      const Linear* Ls = &linears[(size_t)l * nlin];
+      if (!mlp_small_bwd_applicable(Ls, nlin, desc.event_dim)) continue;
+      any = true;
+      span = std::max(span, Ls[nlin - 1].b_off + Ls[nlin - 1].N - Ls[0].w_off);
+    }
+    if (any) NF_HIP(hipMalloc(&b.d_small_partials, span * mlp_small_bwd_max_blocks() * sizeof(float)));
+  }
   std::vector<TransposeJob> jobs(linears.size());
   for (size_t q = 0; q < linears.size(); ++q)
     jobs[q] = TransposeJob{(unsigned long long)linears[q].w_off, (unsigned long long)b.wT_off[q], linears[q].K,
@@ -540,14 +571,30 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
                            par, gld);
       } else {
         const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
-        const dim3 grid(grid_for(n * Dt));
-        if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else hipLaunchKernelGGL((rqs_masked_bwd_kernel<32>), grid, dim3(256), 0, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(4096, (n * Dt + 255) / 256)));
+        const size_t lds = (size_t)2 * 256 * (3 * rc.K + 1) * sizeof(float);  // K = 32: 99 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+          attr_set = true;
+        }
+        if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        else hipLaunchKernelGGL((rqs_masked_bwd_kernel<32>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
       }
       NF_HIP(hipGetLastError());
       // 4. MLP backward
+      if (b.d_small_partials != nullptr && mlp_small_bwd_applicable(Ls, nlin, D)) {
+        const float* acts[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j + 1 < nlin; ++j) acts[j] = recorded(j);
+        NF_TRY(launch_mlp_small_bwd(vc, D, Ls, nlin, d_weights, acts, dth, act, gc, D, b.d_small_partials, b.d_grad, n,
+                                    stream));
+        continue;
+      }
       const float* gcur = dth;
       for (int j = nlin - 1; j >= 0; --j) {
         const Linear& L = Ls[j];

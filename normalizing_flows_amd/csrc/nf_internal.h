@@ -213,6 +213,7 @@ struct Plan {
     int transpose_blocks = 1;
     float* d_zero = nullptr;         // zero bias for the data-gradient GEMMs
     float* d_partials = nullptr;     // weight-gradient partial sums, one slab per row chunk
+    float* d_small_partials = nullptr;  // narrow conditioners (nf_mlp_small_bwd.hip): one slab per workgroup
     size_t partial_floats = 0;
     float* d_scratch = nullptr;
     long long scratch_rows = 0;
@@ -267,6 +268,12 @@ __device__ __forceinline__ void block_to_tile(int id, int gx, int gy, int& mb, i
 bool mlp_small_applicable(const Linear* Ls, int nlin);
 int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights, int act,
                      float* const* outs, long long rows, hipStream_t stream);
+// nf_mlp_small_bwd.hip: the MLP backward of such a conditioner in one launch (+ the workgroup reduction)
+bool mlp_small_bwd_applicable(const Linear* Ls, int nlin, int D);
+int mlp_small_bwd_max_blocks();
+int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights,
+                         const float* const* acts, const float* dth, int act, float* G, int D, float* partial,
+                         float* grad, long long rows, hipStream_t stream);
 size_t x3_image_halfwords(int K, int N);
 void pack_w_x3(const float* W /*[K][N]*/, int K, int N, unsigned short* image);
 bool gemm_x3_applicable(const float* A, int lda, int N, int K);

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "nf_bf16x3.h"
+#include "nf_internal.h"  // block_to_tile
 using nf::bf16x3::bf16x8;
 using nf::bf16x3::f32x16;
 using nf::bf16x3::split_pair;
@@ -25,10 +26,9 @@ __global__ __launch_bounds__(256, OCC) void probe(const float* __restrict__ A, i
   extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int mb = id / gx, nb = id % gx, m0 = mb * XBM, n0 = nb * XBN;
+  int mb, nb;
+  nf::generic::block_to_tile(blockIdx.x, gx, gy, mb, nb);
+  const int m0 = mb * XBM, n0 = nb * XBN;
   const int nk = K / XBK;
   const int arow = tid >> 1, akq = tid & 1;
   const float* arow_ptr = A + (size_t)(m0 + arow) * lda + akq * 8;

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "nf_bf16x3.h"
+#include "nf_internal.h"  // block_to_tile
 using nf::bf16x3::bf16x8;
 using nf::bf16x3::f32x16;
 using nf::bf16x3::split_pair;
@@ -18,10 +19,9 @@ __global__ __launch_bounds__(256, OCC) void wide(const float* __restrict__ A, in
                                                float* __restrict__ Cm, int ldc, int M, int N, int K, int gx, int gy) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds_u4[];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, i = lane & 31, h = lane >> 5;
-  int id = blockIdx.x;
-  const int nblk = gx * gy;
-  if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-  const int mb = id / gx, nb = id % gx, m0 = mb * XBM, n0 = nb * 256;
+  int mb, nb;
+  nf::generic::block_to_tile(blockIdx.x, gx, gy, mb, nb);
+  const int m0 = mb * XBM, n0 = nb * 256;
   const int nk = K / XBK;
   const int c = tid & 7, ar0 = tid >> 3;
   const float* aline_ptr = A + (size_t)(m0 + ar0) * lda + c * 4;
