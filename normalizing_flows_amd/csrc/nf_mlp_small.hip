@@ -36,6 +36,24 @@ constexpr int kTileStride = 65;
 
 constexpr int kWFloats = 64 * 64 + 64;  // one Linear's staged weights + bias
 
+// acc (+)= T [32][K] x Ws [K][N] in groups of four k steps (no branch inside: the LDS reads of a group run ahead
+// of its MFMAs).  Reads up to 7 columns / rows past K: the caller guarantees zeros there on both sides.
+template <bool N2>
+__device__ __forceinline__ void mlp_tile_product(f32x16 (&acc)[2], const float* T, const float* Ws, int K, int i,
+                                                 int h) {
+  const int groups = (K + 7) >> 3;
+  for (int g = 0; g < groups; ++g) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int s = 4 * g + s4;
+      const float av = T[i * kTileStride + 2 * s + h];
+      const float* w = Ws + (2 * s + h) * 64 + i;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[0], acc[0], 0, 0, 0);
+      if (N2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[32], acc[1], 0, 0, 0);
+    }
+  }
+}
+
 template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [nlin][kWFloats] then [4 waves][32 * kTileStride]
@@ -56,33 +74,53 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
   const long long tiles = (a.rows + 31) / 32;
   for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += (long long)gridDim.x * kWaves) {
     const long long row0 = tile * 32;
-    // the wave's 32 input rows: K[0] columns and one zero column behind them (an odd K reads it; what
-    // lies further right is the previous tile's and is never read by this Linear)
-    const int k0w = a.K[0] + 1;
-    for (int q = lane; q < 32 * k0w; q += 64) {
-      const int r = q / k0w, k = q - r * k0w;
-      const long long row = row0 + r;
-      T[r * kTileStride + k] = (row < a.rows && k < a.K[0]) ? a.x[row * a.ldx + k] : 0.f;
+    // the wave's 32 input rows, zero beyond K[0] (all 64 columns) and beyond `rows`.  No predicated load (each
+    // would cost a memory latency of its own): addresses are clamped, zeros come from a select.  Up to 8 input
+    // columns with a dense matrix: the tile is one contiguous run, four loads per lane cover it; wider inputs
+    // take one row per instruction, all 32 in flight.
+    {
+      const int K0 = a.K[0];
+      const long long last = a.rows - 1;
+      if (K0 <= 8 && a.ldx == K0) {
+        const long long e0 = row0 * K0, elast = a.rows * K0 - 1;
+        const unsigned magic = ((1u << 20) + K0 - 1) / K0;  // e / K0 == (e * magic) >> 20 for e < 2048, K0 <= 64
+        float v[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const long long e = e0 + lane + 64 * it;
+          v[it] = a.x[e < elast ? e : elast];
+        }
+        for (int q = lane; q < 32 * 16; q += 64) T[(q >> 4) * kTileStride + (q & 15)] = 0.f;  // what the product reads
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const unsigned e = lane + 64 * it;
+          const unsigned r = (e * magic) >> 20, k = e - r * K0;
+          if (e < 32u * K0 && row0 + r <= last) T[r * kTileStride + k] = v[it];
+        }
+      } else {
+        float v[32];
+        const int col = lane < K0 ? lane : K0 - 1;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+          long long row = row0 + r;
+          row = row < last ? row : last;
+          v[r] = a.x[row * a.ldx + col];
+        }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) T[r * kTileStride + lane] = (lane < K0 && row0 + r <= last) ? v[r] : 0.f;
+      }
     }
     for (int j = 0; j < a.nlin; ++j) {
       const int K = a.K[j], N = a.N[j];
       const float* Ws = smem + j * kWFloats;
       const float* bs = Ws + 4096;
-      const int ntiles = (N + 31) >> 5, steps = (K + 1) >> 1;
+      const int ntiles = (N + 31) >> 5;
       f32x16 acc[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-      if (ntiles > 1) {
-        for (int s = 0; s < steps; ++s) {
-          const float av = T[i * kTileStride + 2 * s + h];
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(2 * s + h) * 64 + i], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(2 * s + h) * 64 + 32 + i], acc[1], 0, 0, 0);
-        }
-      } else {
-        for (int s = 0; s < steps; ++s)
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(T[i * kTileStride + 2 * s + h], Ws[(2 * s + h) * 64 + i],
-                                                        acc[0], 0, 0, 0);
-      }
+      // every column of T is defined (zeros beyond this Linear's K) and Ws is zero padded to 64 x 64
+      if (ntiles > 1) mlp_tile_product<true>(acc, T, Ws, K, i, h);
+      else mlp_tile_product<false>(acc, T, Ws, K, i, h);
       // bias + activation, back over the wave's own tile (all its reads are done), and out to HBM if wanted
       float* out = a.out[j];
       const int act = a.act[j];
