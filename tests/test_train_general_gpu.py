@@ -280,3 +280,30 @@ def test_leaky_relu_conditioner_forward_and_gradient(nfa, kind):
                                          spec.num_bins, spec.range_min, spec.range_max), x)
     assert np.abs(relu_spec_lp - ref).max() > 1e-3      # the activation matters on this data
     check_grads(f, spec, x)
+
+
+@pytest.mark.parametrize("kind,D,hidden,K,rows", [("rqs", 2, (64, 64), 12, 5000), ("rqs", 5, (24,), 8, 33),
+                                                  ("rqs", 3, (48, 40, 56), 4, 1), ("affine", 2, (50, 50), 0, 4097),
+                                                  ("affine", 6, (64, 64, 64), 0, 777), ("affine", 7, (16,), 0, 130)])
+def test_narrow_backward_both_forms(nfa, monkeypatch, kind, D, hidden, K, rows):
+    """Narrow conditioners (every Linear <= 64 wide): the one-launch MLP backward (nf_mlp_small_bwd.hip: one, two
+    and three hidden layers, odd D, one to many workgroups, ragged last tile) and the generic per-Linear form
+    (NF_NO_MLP_SMALL_BWD) against the oracle and against each other."""
+    if kind == "rqs":
+        spec = O.make_rqs_spec(3, event_size=D, hidden=hidden, num_bins=K, range_min=-4.0, range_max=4.0,
+                               final_std=0.05, first_parity=1)
+        make = lambda: rqs_flow(nfa, spec, 1)
+    else:
+        spec = O.make_affine_spec(3, event_size=D, hidden=hidden, final_std=0.05, first_parity=1)
+        make = lambda: affine_flow(nfa, spec, 1)
+    x = (np.random.default_rng(D * 7 + rows).standard_normal((rows, D)) * 1.5).astype(np.float32)
+    f = make()
+    fused, ref = check_grads(f, spec, x, tol=3e-4 if rows < 64 else 2e-4)
+    monkeypatch.setenv("NF_NO_MLP_SMALL_BWD", "1")
+    g = make()
+    generic, _ = check_grads(g, spec, x, tol=3e-4 if rows < 64 else 2e-4)
+    for l in range(len(spec.layers)):
+        for j in range(len(spec.layers[l])):
+            for which in (0, 1):
+                scale = max(np.abs(ref[l][j][which]).max(), 1e-6)
+                assert np.abs(fused[l][j][which] - generic[l][j][which]).max() <= 4e-4 * scale
