@@ -122,6 +122,15 @@ struct nf_flow {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_weights = false;
   size_t weight_count = 0;
+  // 2-D masked flows with two hidden layers narrower than 64 (the reference scripts default to 50) run on the
+  // fused 64/64 kernels: hidden units are added with zero weights and biases (relu(0) = 0: they contribute
+  // exact zeros to every sum, receive zero gradients and stay zero under SGD / Adam).  `desc` and
+  // `weight_count` then describe the padded flow; the caller keeps seeing its own layout through pad_map.
+  bool padded = false;
+  size_t user_count = 0;       // weights in the caller's layout (== weight_count unless padded)
+  std::vector<int> pad_map;    // caller's index -> padded index
+  int* d_pad_map = nullptr;
+  float* d_pad_tmp = nullptr;  // [user_count]
   float* d_wimg = nullptr;  // path-specific packed weights
   // PATH_AFFINE2D_H64 with nf_flow_set_option("hidden_matmul", "bf16x3"): a second image, rebuilt
   // lazily from the canonical weights whenever they changed
@@ -163,6 +172,8 @@ struct nf_flow {
   double* h_reduce = nullptr;   // pinned, NF_NLL_SLOTS
 };
 
+static int get_weights_internal(nf_flow* f, float* packed, size_t count);  // the handle's own (padded) layout
+
 namespace nf {
 
 static int ensure_stage(nf_flow* f, long long rows) {
@@ -188,10 +199,21 @@ static void direction_flags(int direction, int* descending, int* inverse_op) {
   }
 }
 
+__global__ __launch_bounds__(256) void gather_f32_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                         const int* __restrict__ idx, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) dst[q] = src[idx[q]];
+}
+static int launch_gather(float* dst, const float* src, const int* idx, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, stream, dst,
+                     src, idx, n);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 static int refresh_x3_image(nf_flow* f) {
   const nf_flow_desc& d = f->desc;
   std::vector<float> w(f->weight_count);
-  NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));
+  NF_TRY(::get_weights_internal(f, w.data(), w.size()));
   const size_t per_layer = f->weight_count / d.num_layers;
   const bool rqs = f->path == PATH_RQS2D_H64;
   const size_t image_floats = rqs ? rqs2d_x3::kLayerFloats : affine2d_x3::kLayerFloats;
@@ -303,7 +325,7 @@ static void pack_rqs_images(const nf_flow_desc& d, const float* packed, size_t p
 
 static int refresh_rqs_image(nf_flow* f) {
   std::vector<float> w(f->weight_count), img;
-  NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));  // synchronises, downloads the trained weights
+  NF_TRY(::get_weights_internal(f, w.data(), w.size()));  // synchronises, downloads the trained weights
   pack_rqs_images(f->desc, w.data(), f->weight_count / f->desc.num_layers, img);
   NF_HIP(hipMemcpy(f->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
   f->wimg_stale = false;
@@ -412,7 +434,35 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
   nf_flow* f = new (std::nothrow) nf_flow();
   if (!f) { set_error("out of host memory"); return NF_ERR_INVALID; }
   f->desc = *desc;
-  nf_flow_weight_count(desc, &f->weight_count);
+  nf_flow_weight_count(desc, &f->user_count);
+  {
+    const nf_flow_desc& u = *desc;
+    const bool fused_kind = u.kind == NF_KIND_AFFINE_MASKED ||
+                            (u.kind == NF_KIND_RQS_MASKED && rqs2d::supported_bins(u.rqs_bins) &&
+                             getenv("NF_FORCE_GENERIC") == nullptr);
+    if (fused_kind && u.event_dim == 2 && u.num_hidden == 2 && u.activation == NF_ACT_RELU && u.hidden[0] <= 64 &&
+        u.hidden[1] <= 64 && (u.hidden[0] < 64 || u.hidden[1] < 64) && getenv("NF_NO_PAD") == nullptr) {
+      f->padded = true;
+      f->desc.hidden[0] = f->desc.hidden[1] = 64;
+      std::vector<int> in, out;
+      linear_shapes(u, in, out);  // the caller's shapes; the padded ones differ in hidden widths only
+      const int pin[3] = {in[0], 64, 64}, pout[3] = {64, 64, out[2]};
+      size_t pper = 0;
+      for (int j = 0; j < 3; ++j) pper += (size_t)pin[j] * pout[j] + pout[j];
+      f->pad_map.reserve(f->user_count);
+      for (int l = 0; l < u.num_layers; ++l) {
+        size_t base = pper * l;
+        for (int j = 0; j < 3; ++j) {
+          for (int k = 0; k < in[j]; ++k)
+            for (int n = 0; n < out[j]; ++n) f->pad_map.push_back((int)(base + (size_t)k * pout[j] + n));
+          base += (size_t)pin[j] * pout[j];
+          for (int n = 0; n < out[j]; ++n) f->pad_map.push_back((int)(base + n));
+          base += pout[j];
+        }
+      }
+    }
+  }
+  nf_flow_weight_count(&f->desc, &f->weight_count);
   const nf_flow_desc& d = f->desc;
   if (d.kind == NF_KIND_AFFINE_MASKED && d.event_dim == 2 && d.num_hidden == 2 &&
       d.hidden[0] == 64 && d.hidden[1] == 64 && d.activation == NF_ACT_RELU)
@@ -489,19 +539,30 @@ void nf_flow_destroy(nf_flow* f) {
   hipFree(f->d_block_sums); hipFree(f->d_sum); hipFree(f->d_reduce);
   if (f->h_ring) hipHostFree(f->h_ring);
   if (f->h_reduce) hipHostFree(f->h_reduce);
+  hipFree(f->d_pad_map);
+  hipFree(f->d_pad_tmp);
   if (f->ev0) hipEventDestroy(f->ev0);
   if (f->ev1) hipEventDestroy(f->ev1);
   if (f->stream) hipStreamDestroy(f->stream);
   delete f;
 }
 
+static int set_weights_internal(nf_flow* f, const float* packed, size_t count);
+
 int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   if (!packed) { set_error("packed is NULL"); return NF_ERR_INVALID; }
-  if (count != f->weight_count) {
-    set_error("expected %zu float32 weights for this flow, got %zu", f->weight_count, count);
+  if (count != f->user_count) {
+    set_error("expected %zu float32 weights for this flow, got %zu", f->user_count, count);
     return NF_ERR_INVALID;
   }
+  if (!f->padded) return set_weights_internal(f, packed, count);
+  std::vector<float> wide(f->weight_count, 0.f);
+  for (size_t q = 0; q < count; ++q) wide[f->pad_map[q]] = packed[q];
+  return set_weights_internal(f, wide.data(), wide.size());
+}
+
+static int set_weights_internal(nf_flow* f, const float* packed, size_t count) {
   const nf_flow_desc& d = f->desc;
   std::vector<int> in, out;
   linear_shapes(d, in, out);
@@ -1088,7 +1149,17 @@ int nf_nll_grad(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_glo
   const float* x_dev = nullptr;
   NF_TRY(stage_train_input(f, x, rows_local, mem, &x_dev));
   NF_TRY(enqueue_nll_grad(f, x_dev, rows_local, rows_global));
-  NF_HIP(hipMemcpyAsync(out_grad, f->train.d_grad, f->weight_count * sizeof(float),
+  const float* grad = f->train.d_grad;
+  if (f->padded) {  // the caller's layout: its entries of the padded gradient
+    if (!f->d_pad_map) {
+      NF_HIP(hipMalloc(&f->d_pad_map, f->user_count * sizeof(int)));
+      NF_HIP(hipMalloc(&f->d_pad_tmp, f->user_count * sizeof(float)));
+      NF_HIP(hipMemcpy(f->d_pad_map, f->pad_map.data(), f->user_count * sizeof(int), hipMemcpyHostToDevice));
+    }
+    NF_TRY(launch_gather(f->d_pad_tmp, f->train.d_grad, f->d_pad_map, f->user_count, f->stream));
+    grad = f->d_pad_tmp;
+  }
+  NF_HIP(hipMemcpyAsync(out_grad, grad, f->user_count * sizeof(float),
                         mem == NF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, f->stream));
   NF_TRY(nf_flow_synchronize(f));
   if (out_nll) NF_TRY(nf_nll_result(f, 0, out_nll));
@@ -1126,7 +1197,7 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
     if (f->plan.x3) {  // the split-bf16 weight images are built on the host
       std::vector<float> w(f->weight_count);
       t.dirty = true;
-      NF_TRY(nf_flow_get_weights(f, w.data(), w.size()));
+      NF_TRY(::get_weights_internal(f, w.data(), w.size()));
       NF_TRY(f->plan.build(d_of(f), w.data()));
       NF_TRY(f->plan.prepare_backward());
     }
@@ -1143,7 +1214,15 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
 int nf_flow_get_weights(nf_flow* f, float* packed, size_t count) {
   if (!f || !packed) { set_error("bad argument"); return NF_ERR_INVALID; }
   if (!f->have_weights) { set_error("nf_flow_set_weights has not been called"); return NF_ERR_STATE; }
-  if (count != f->weight_count) { set_error("expected room for %zu weights, got %zu", f->weight_count, count); return NF_ERR_INVALID; }
+  if (count != f->user_count) { set_error("expected room for %zu weights, got %zu", f->user_count, count); return NF_ERR_INVALID; }
+  if (!f->padded) return get_weights_internal(f, packed, count);
+  std::vector<float> wide(f->weight_count);
+  NF_TRY(get_weights_internal(f, wide.data(), wide.size()));
+  for (size_t q = 0; q < count; ++q) packed[q] = wide[f->pad_map[q]];
+  return NF_OK;
+}
+
+static int get_weights_internal(nf_flow* f, float* packed, size_t count) {
   if (f->train.ready && f->train.dirty) {
     NF_TRY(nf_flow_synchronize(f));
     NF_HIP(hipMemcpy(f->h_weights.data(), f->path == PATH_SPLIT2D_SMALL ? f->d_wimg : f->train.d_canon,

@@ -1,5 +1,7 @@
-"""log_prob rate of 2-D flows whose conditioner is NOT the fused kernels' 64/64 (general path): one launch
-per conditioner (nf_mlp_small.hip) against the GEMM chain (NF_NO_MLP_SMALL=1).  python profiles/narrow_flows.py"""
+"""log_prob rate of 2-D flows whose conditioner is NOT the fused kernels' 64/64: as shipped (two hidden layers up to
+64 wide are zero-padded onto the fused kernels by nf_flow_create), on the general path with one launch per
+conditioner (NF_NO_PAD=1: nf_mlp_small.hip) and with the GEMM chain (+ NF_NO_MLP_SMALL=1).
+python profiles/narrow_flows.py"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,12 +28,13 @@ def one():
         for _ in range(10):
             f.log_prob(x, out)
         ms = f.timer_stop() / 10
-        print(f"{'GEMM chain ' if os.environ.get('NF_NO_MLP_SMALL') else 'one launch '} {name:18s} {f.kernel_name}: "
+        label = "GEMM chain" if os.environ.get("NF_NO_MLP_SMALL") else ("one launch" if os.environ.get("NF_NO_PAD") else "as shipped")
+        print(f"{label:11s} {name:18s} {f.kernel_name}: "
               f"{ms:7.3f} ms per 2^20 rows x 8 layers = {rows / ms / 1e3:7.1f} M evals/s", flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         one()
     else:
-        for env in ({}, {"NF_NO_MLP_SMALL": "1"}):
+        for env in ({}, {"NF_NO_PAD": "1"}, {"NF_NO_PAD": "1", "NF_NO_MLP_SMALL": "1"}):
             subprocess.run([sys.executable, __file__, "one"], env=dict(os.environ, **env), check=True)

@@ -51,13 +51,34 @@ def nfa(nf_lib):
     return flow
 
 
-def affine_flow(nfa, spec, parity=1):
+class _no_pad:
+    """2-D masked flows with two hidden layers narrower than 64 are zero-padded onto the fused 64/64 kernels by
+    default (nf_flow_create).  The tests written for the general path keep it: NF_NO_PAD is read at creation."""
+    def __init__(self, pad):
+        self.pad = pad
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("NF_NO_PAD")
+        if not self.pad:
+            os.environ["NF_NO_PAD"] = "1"
+
+    def __exit__(self, *exc):
+        import os
+        if self.old is None:
+            os.environ.pop("NF_NO_PAD", None)
+        else:
+            os.environ["NF_NO_PAD"] = self.old
+
+
+def affine_flow(nfa, spec, parity=1, pad=False):
     from normalizing_flows_amd import _lib
     cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=spec.event_size,
                          num_layers=len(spec.layers),
                          hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]),
                          first_mask_parity=parity)
-    return nfa.CouplingFlow(cfg, spec.layers)
+    with _no_pad(pad):
+        return nfa.CouplingFlow(cfg, spec.layers)
 
 
 def split_flow(nfa, params, first_flip=0):
@@ -323,13 +344,14 @@ def test_rccl_single_rank_allreduce(nfa):
 
 
 # ------------------------------------------------------------------ general path (GEMM chain + transforms)
-def rqs_flow(nfa, spec, parity=1):
+def rqs_flow(nfa, spec, parity=1, pad=False):
     from normalizing_flows_amd import _lib
     cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=spec.event_size, num_layers=len(spec.layers),
                          hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]), first_mask_parity=parity,
                          base=_lib.BASE_STD_NORMAL if spec.base == "normal" else _lib.BASE_UNIFORM01,
                          rqs_bins=spec.num_bins, rqs_range_min=spec.range_min, rqs_range_max=spec.range_max)
-    return nfa.CouplingFlow(cfg, spec.layers)
+    with _no_pad(pad):
+        return nfa.CouplingFlow(cfg, spec.layers)
 
 
 @pytest.mark.parametrize("D,hidden,L,parity", [(2, (32, 32), 4, 1), (2, (64,), 3, 0), (2, (50, 70), 5, 1),
@@ -617,6 +639,41 @@ def test_rqs_spline_in_gemm_epilogue(nfa, monkeypatch, mode, K, D, hidden, L, ro
     g.set_option("hidden_matmul", mode)
     plain = g.log_prob(x)
     assert np.abs(plain.astype(np.float64) - got).max() <= 2 * max(FLOOR * e32, float(tol(ref).max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("kind,hidden,K", [("affine", (50, 50), 0), ("affine", (32, 64), 0), ("affine", (7, 1), 0),
+                                           ("rqs", (50, 50), 4), ("rqs", (64, 33), 12)])
+def test_narrow_2d_flows_run_on_the_fused_kernels(nfa, mode, kind, hidden, K):
+    """The reference scripts default to two hidden layers of 50 (src/real_nvp_toy_densities.py:249-251,
+    src/maf_toy_densities.py:236-238, K = 4): such flows are zero-padded to 64/64 inside nf_flow_create and run on
+    the fused kernels -- same log_prob, walks and weights as the caller's layout says."""
+    from normalizing_flows_amd import _lib
+    if kind == "affine":
+        spec = O.make_affine_spec(8, hidden=hidden, final_std=0.03)
+        f = affine_flow(nfa, spec, pad=True)
+        assert f.kernel_name == "affine2d_h64_mfma"
+    else:
+        spec = O.make_rqs_spec(8, hidden=hidden, num_bins=K, final_std=0.05)
+        f = rqs_flow(nfa, spec, pad=True)
+        assert f.kernel_name == "rqs2d_h64_mfma"
+    f.set_option("hidden_matmul", mode)
+    x = O.make_inputs("banana", 5000, seed=len(hidden) + K)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max() if kind == "rqs" else 0.0
+    assert_close(f.log_prob(x), ref, "padded log_prob", FLOOR * e32)
+    assert abs(f.nll(x) - O.nll(spec, x)) <= 1e-5 * max(1.0, abs(O.nll(spec, x)))
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    z32, l32 = O.chain_forward(spec, x, np.float32)
+    assert_close(z, zr, "padded forward", FLOOR * np.abs(z32 - zr).max() if kind == "rqs" else 0.0)
+    assert_close(ld, ldr, "padded forward logdet", FLOOR * np.abs(l32 - ldr).max() if kind == "rqs" else 0.0)
+    # the caller's weights come back in the caller's layout
+    got = f.get_weights()
+    for l in range(8):
+        for j in range(3):
+            assert np.array_equal(got[l][j][0], np.asarray(spec.layers[l][j][0], np.float32))
+            assert np.array_equal(got[l][j][1], np.asarray(spec.layers[l][j][1], np.float32))
 
 
 # ------------------------------------------------------------------ backward pass / training step

@@ -307,3 +307,48 @@ def test_narrow_backward_both_forms(nfa, monkeypatch, kind, D, hidden, K, rows):
             for which in (0, 1):
                 scale = max(np.abs(ref[l][j][which]).max(), 1e-6)
                 assert np.abs(fused[l][j][which] - generic[l][j][which]).max() <= 4e-4 * scale
+
+
+@pytest.mark.parametrize("kind", ["affine", "rqs"])
+def test_padded_narrow_flow_trains_in_the_callers_layout(nfa, kind):
+    """hidden 50/50 (the reference scripts' default) on the fused kernels through zero padding: gradients arrive in
+    the caller's layout and match the oracle, three Adam steps follow optax.adam restated in float64 (the padding
+    units receive zero gradients and stay zero: the flow after training is still the caller's 50/50 flow), SGD
+    moves the weights by exactly -lr * gradient."""
+    from normalizing_flows_amd import training
+    if kind == "affine":
+        spec = O.make_affine_spec(4, hidden=(50, 50), final_std=0.03)
+        f = affine_flow(nfa, spec, pad=True)
+        assert f.kernel_name == "affine2d_h64_mfma"
+        fresh = lambda: O.make_affine_spec(4, hidden=(50, 50), final_std=0.03)
+    else:
+        spec = O.make_rqs_spec(4, hidden=(50, 50), num_bins=4, final_std=0.05)
+        f = rqs_flow(nfa, spec, pad=True)
+        assert f.kernel_name == "rqs2d_h64_mfma"
+        fresh = lambda: O.make_rqs_spec(4, hidden=(50, 50), num_bins=4, final_std=0.05)
+    x = O.make_inputs("banana", 3000, seed=11)
+    check_grads(f, spec, x)
+    opt = training.adam(1e-3)
+    p = _flat([[(W.astype(np.float64), b.astype(np.float64)) for W, b in layer] for layer in spec.layers])
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for step in range(1, 4):
+        xb = O.make_inputs("gaussian_blobs", 2048, seed=70 + step)
+        loss = f.train_step(xb, opt)
+        cur = fresh()
+        cur.layers = f.unpack_weights(p.astype(np.float64))
+        rl, rg = O.flow_nll_and_grad(cur, xb)
+        assert abs(loss - rl) <= 2e-5 * max(1.0, abs(rl)), (step, loss, rl)
+        p, m, v = O.adam_reference(p, _flat(rg), m, v, step, 1e-3)
+    got = _flat(f.get_weights())
+    assert got.shape == p.shape
+    assert np.abs(got - p).max() <= 0.05 * 3 * 1e-3, np.abs(got - p).max()
+    new_spec = fresh()
+    new_spec.layers = f.get_weights()
+    ref = O.log_prob(new_spec, x)
+    e32 = np.abs(O.log_prob(new_spec, x, np.float32) - ref).max() if kind == "rqs" else 0.0
+    assert_close(f.log_prob(x), ref, "padded flow after training", 4 * e32)
+    g_before = f.nll_grad(x)[1]
+    w_before = _flat(f.get_weights())
+    f.train_step(x, training.sgd(0.01))
+    assert np.abs(_flat(f.get_weights()) - (w_before - 0.01 * _flat(g_before))).max() <= 1e-6
