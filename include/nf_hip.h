@@ -124,7 +124,12 @@ int nf_flow_weight_count(const nf_flow_desc* desc, size_t* out_count);
 
 /* Replaces make_flow_model (src/real_nvp_toy_densities.py:74-110,
    src/maf_toy_densities.py:74-111, src/maf_mnist.py:52-89) and init_nvp_chain's
-   structure (src/real_nvp.py:198-220): builds the chain on the current device. */
+   structure (src/real_nvp.py:198-220): builds the chain on the current device.
+   Kernel choice is by shape: 2-D masked flows with two relu hidden layers of at most 64 units
+   (the scripts default to --hidden_size 50, src/real_nvp_toy_densities.py:249-251) run on the fused
+   64/64 kernels -- narrower layers are completed with zero-weight units inside the handle, every
+   weight / gradient vector that crosses this ABI keeps the layout `desc` describes (environment
+   NF_NO_PAD=1: keep such flows on the general path); other shapes take the general path. */
 int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow);
 void nf_flow_destroy(nf_flow* flow);
 
