@@ -1004,22 +1004,26 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
     for (int li = 0; li < nlay; ++li) {
       const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
       const int par = (d.first_mask_parity + l) & 1;  // masked: pass-through parity; split: flip
-      if (record_tape)  // training: keep every layer's input (indexed by LAYER, not by position)
-        NF_HIP(hipMemcpyAsync(bwd.d_tape + ((size_t)l * bwd.tape_rows + r0) * D, yc, sizeof(float) * n * D,
-                              hipMemcpyDeviceToDevice, stream));
       const float* a = yc;
       int lda = D;
       if (d.kind == NF_KIND_AFFINE_SPLIT && par) a = yc + D / 2;  // flipped: second half conditions
       const Linear* Ls = &linears[(size_t)l * nlin];
       bool fused_transform = false;
-      if (!(x3 && d_wx3) && mlp_small_applicable(Ls, nlin)) {
+      const bool narrow = !(x3 && d_wx3) && mlp_small_applicable(Ls, nlin);
+      // training: keep every layer's input (indexed by LAYER, not by position); the narrow conditioner's
+      // kernel writes it while it loads its input tile
+      float* tape = record_tape ? bwd.d_tape + ((size_t)l * bwd.tape_rows + r0) * D : nullptr;
+      const bool tape_in_kernel = narrow && a == yc && Ls[0].K == D;
+      if (record_tape && !tape_in_kernel)
+        NF_HIP(hipMemcpyAsync(tape, yc, sizeof(float) * n * D, hipMemcpyDeviceToDevice, stream));
+      if (narrow) {
         // narrow conditioner: one launch, activations stay in LDS (recorded only for the training walk)
         float* outs[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int j = 0; j < nlin; ++j) {
           if (record_tape) outs[j] = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * Ls[j].N;
           else if (j == nlin - 1) outs[j] = buf[2];
         }
-        NF_TRY(launch_mlp_small(a, lda, Ls, nlin, d_weights, act, outs, n, stream));
+        NF_TRY(launch_mlp_small(a, lda, Ls, nlin, d_weights, act, outs, n, stream, tape_in_kernel ? tape : nullptr));
         a = outs[nlin - 1];
       } else
       for (int j = 0; j < nlin; ++j) {

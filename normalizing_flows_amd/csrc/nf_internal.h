@@ -266,8 +266,9 @@ __device__ __forceinline__ void block_to_tile(int id, int gx, int gy, int& mb, i
 
 // nf_mlp_small.hip: a whole conditioner (every Linear K, N <= 64) in one launch
 bool mlp_small_applicable(const Linear* Ls, int nlin);
+// tape != null (needs ldx == Ls[0].K): the input rows are also copied there, dense
 int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights, int act,
-                     float* const* outs, long long rows, hipStream_t stream);
+                     float* const* outs, long long rows, hipStream_t stream, float* tape = nullptr);
 // nf_mlp_small_bwd.hip: the MLP backward of such a conditioner in one launch (+ the workgroup reduction)
 bool mlp_small_bwd_applicable(const Linear* Ls, int nlin, int D);
 int mlp_small_bwd_max_blocks();

@@ -29,6 +29,7 @@ struct MlpSmallArgs {
   int K[4], N[4];
   int act[4];          // 0 none, 1 relu, 2 leaky_relu
   float* out[4];       // [rows][N] dense, or null (hidden activations nobody needs)
+  float* tape;         // training walk: the input rows are copied here ([rows][K[0]] dense, ldx == K[0]), or null
   long long rows;
 };
 
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
         for (int it = 0; it < 4; ++it) {
           const unsigned e = lane + 64 * it;
           const unsigned r = (e * magic) >> 20, k = e - r * K0;
-          if (e < 32u * K0 && row0 + r <= last) T[r * kTileStride + k] = v[it];
+          if (e < 32u * K0 && row0 + r <= last) {
+            T[r * kTileStride + k] = v[it];
+            if (a.tape != nullptr) a.tape[e0 + e] = v[it];
+          }
         }
       } else {
         float v[32];
@@ -108,6 +112,10 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
         }
 #pragma unroll
         for (int r = 0; r < 32; ++r) T[r * kTileStride + lane] = (lane < K0 && row0 + r <= last) ? v[r] : 0.f;
+        if (a.tape != nullptr && lane < K0)
+#pragma unroll
+          for (int r = 0; r < 32; ++r)
+            if (row0 + r <= last) a.tape[(row0 + r) * K0 + lane] = v[r];
       }
     }
     for (int j = 0; j < a.nlin; ++j) {
@@ -156,8 +164,9 @@ bool mlp_small_applicable(const Linear* Ls, int nlin) {
 
 // One coupling layer's conditioner: x [rows][ldx] -> out[nlin-1] (= theta), hidden outputs optional.
 int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights, int act,
-                     float* const* outs, long long rows, hipStream_t stream) {
+                     float* const* outs, long long rows, hipStream_t stream, float* tape) {
   MlpSmallArgs a;
+  a.tape = tape;
   a.x = x;
   a.ldx = ldx;
   a.nlin = nlin;

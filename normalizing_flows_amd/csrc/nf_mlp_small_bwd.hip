@@ -36,6 +36,7 @@ struct MlpSmallBwdArgs {
   float* G;             // [rows][D]: += g_0 W_1^T
   int D;
   float* partial;       // [gridDim.x][span]: this workgroup's sums, in the plan's weight layout of the layer
+  float* grad_direct;   // one workgroup only: the layer's span of the gradient itself, added to in place
   int span;
   int w_rel[4], b_rel[4];  // where dW_j / db_j sit inside a slab
   long long rows;
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
   // join the four waves' sums in a fixed order; the tile area is free once every wave is done
   __syncthreads();
   float* red = tiles_base;  // [4 waves][1024]
-  float* slab = a.partial + (size_t)blockIdx.x * a.span;
+  const bool direct = a.grad_direct != nullptr;  // small batches: no slab, no reduction launch
+  float* slab = direct ? a.grad_direct : a.partial + (size_t)blockIdx.x * a.span;
 #pragma unroll
   for (int j = 0; j < NLIN; ++j) {
     const int K = a.K[j], N = a.N[j];
@@ -249,8 +251,11 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
         for (int e = tid; e < 1024; e += 256) {
           const int r = e >> 6, l = e & 63;
           const int kk = 32 * p + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), nn = 32 * q + (l & 31);
-          if (kk < K && nn < N)
-            slab[a.w_rel[j] + kk * N + nn] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+          if (kk < K && nn < N) {
+            const float t = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+            float* dst = slab + a.w_rel[j] + kk * N + nn;
+            *dst = direct ? *dst + t : t;
+          }
         }
         __syncthreads();
       }
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[w * 128 + q * 64 + c] + red[w * 128 + q * 64 + 32 + c];
-      slab[a.b_rel[j] + tid] = s;
+      slab[a.b_rel[j] + tid] = direct ? slab[a.b_rel[j] + tid] + s : s;
     }
     __syncthreads();
   }
@@ -326,12 +331,15 @@ int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, co
   const size_t lds_bytes = ((size_t)nlin * 4096 + (size_t)4 * 2 * kBwdTileFloats) * sizeof(float);
   const long long tiles = (rows + 31) / 32;
   const int blocks = (int)std::max<long long>(1, std::min<long long>(mlp_small_bwd_max_blocks(), (tiles + 3) / 4));
-  NF_HIP(hipMemsetAsync(partial, 0, (size_t)blocks * a.span * sizeof(float), stream));  // alignment gaps of the layout
+  a.grad_direct = blocks == 1 ? grad + lo : nullptr;
+  if (blocks > 1)
+    NF_HIP(hipMemsetAsync(partial, 0, (size_t)blocks * a.span * sizeof(float), stream));  // alignment gaps of the layout
   if (nlin == 2) hipLaunchKernelGGL(mlp_small_bwd_kernel<2>, dim3(blocks), dim3(256), lds_bytes, stream, a);
   else if (nlin == 3) hipLaunchKernelGGL(mlp_small_bwd_kernel<3>, dim3(blocks), dim3(256), lds_bytes, stream, a);
   else hipLaunchKernelGGL(mlp_small_bwd_kernel<4>, dim3(blocks), dim3(256), lds_bytes, stream, a);
-  hipLaunchKernelGGL(small_bwd_reduce_kernel, dim3((a.span + 255) / 256), dim3(256), 0, stream, partial, blocks, a.span,
-                     grad + lo);
+  if (blocks > 1)
+    hipLaunchKernelGGL(small_bwd_reduce_kernel, dim3((a.span + 255) / 256), dim3(256), 0, stream, partial, blocks, a.span,
+                       grad + lo);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
