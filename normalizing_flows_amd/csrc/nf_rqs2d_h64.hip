@@ -81,7 +81,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
   const int i = lane & 31, h = lane >> 5;
   const long long rows = io.rows;
   const long long groups = (rows + (T * 32 - 1)) / (T * 32);
-  const long long groups_per_pass = (long long)gridDim.x * WAVES;
+  const int aw = p.active_waves > 0 ? p.active_waves : WAVES;
+  const long long groups_per_pass = (long long)gridDim.x * aw;
   const long long passes = (groups + groups_per_pass - 1) / groups_per_pass;  // same for every block
   const float2* __restrict__ xin = reinterpret_cast<const float2*>(io.x);
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
   double wave_sum = 0.0;
   long long step = 0;  // layers walked so far by this block: selects the LDS buffer
   for (long long pass = 0; pass < passes; ++pass) {
-    const long long g = (pass * gridDim.x + blockIdx.x) * WAVES + wave;
+    // a wave without a group of its own walks the layers' barriers and staging only
+    const bool live = wave < aw && (pass * gridDim.x + blockIdx.x) * aw + wave < groups;
+    const long long g = live ? (pass * gridDim.x + blockIdx.x) * aw + wave : groups;
     const int c_first = (p.first_mask_parity + layer_of(0)) & 1;
     float xc[T], xt[T], ld[T];
     long long idx[T];
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
       const bool more = li + 1 < nlay || pass + 1 < passes;
       if (more) NF_FETCH(li + 1 < nlay ? li + 1 : 0);
 
+      if (live) {
       const float* L = lds + (step & 1) * kLayerFloats;
       const float2* a2 = reinterpret_cast<const float2*>(L + kA2) + lane;
       const float2* a3 = reinterpret_cast<const float2*>(L + kA3) + lane;
@@ -203,6 +207,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
         ld[t] += l;
         xt[t] = xc[t];
         xc[t] = nt;
+      }
+
       }
 
       if (more) NF_STASH((int)((step + 1) & 1));
@@ -293,7 +299,11 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   if (waves != 8) { waves = 16; T = 1; }
   if (T != 2) T = 1;
   const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);
-  long long want = (groups + waves - 1) / waves;
+  // few groups: one per workgroup first (every CU gets a wave before any CU gets two), then more waves each
+  long long aw = (groups + max_grid() - 1) / max_grid();
+  aw = aw < 1 ? 1 : (aw > waves ? waves : aw);
+  p.active_waves = (int)aw;
+  long long want = (groups + aw - 1) / aw;
   // 8-wave workgroups use 67.6 KB of LDS and <= 128 VGPRs: two of them share a CU
   const int cap = waves == 8 ? 2 * max_grid() : max_grid();
   const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
