@@ -22,7 +22,9 @@
 // gemm_x3_probe.hip, gemm_x3_wide_probe.hip): W through LDS, W direct, 128x256 blocks with
 // 128x64 wave tiles (half the vector-memory bytes and split work per MFMA), branch-free prefetch and the
 // split interleaved with the MFMAs all land within 4 % of each other -- the MFMA stream itself runs at
-// 71 % of its nominal rate on dense operands (88 % on zeros: clock/power), and that is what binds.
+// 71 % of its nominal rate on dense operands (88 % on zeros: clock/power), and that is what binds.  The wide
+// geometry won in the probe (-9 %) and lost in this file (+8 % with the spline epilogue, +10 % plain: one
+// workgroup per CU leaves prologue, store and epilogue without another workgroup's MFMAs beside them).
 #include "nf_bf16x3.h"
 #include "nf_internal.h"
 #include "nf_rqs_eval.h"
