@@ -514,9 +514,10 @@ int launch_gather(const float* partials, int nparts, const int* map, const float
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                                                   float b1, float b2, float eps, float c1, float c2) {
+                                                   float b1, float b2, float eps, float c1, float c2,
+                                                   const int* __restrict__ skip) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  if (e >= n || (skip != nullptr && *skip != 0)) return;
   // optax.adam (src/real_nvp_toy_densities.py:162): m, v moments, bias-corrected by c1 = 1-b1^t, c2 = 1-b2^t
   const float ge = g[e];
   const float me = b1 * m[e] + (1.f - b1) * ge;
@@ -526,9 +527,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   w[e] -= lr * (me / c1) / (sqrtf(ve / c2) + eps);
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, size_t n, float lr) {
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, size_t n, float lr,
+                                                  const int* __restrict__ skip) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < n) w[e] -= lr * g[e];  // src/real_nvp.py:298
+  if (e < n && !(skip != nullptr && *skip != 0)) w[e] -= lr * g[e];  // src/real_nvp.py:298
+}
+
+// *flag = 1 when any gradient entry is NaN or infinite (flag zeroed by the caller): the "skip_nonfinite_updates"
+// option, optax.apply_if_finite's test
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, size_t n, int* __restrict__ flag) {
+  bool bad = false;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+    bad |= (__float_as_uint(g[e]) & 0x7f800000u) == 0x7f800000u;
+  if (bad) *flag = 1;
 }
 
 // image[i] = canon[src[i]] * 2^shift[i]  (src < 0: 0)
@@ -541,17 +552,24 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ c
   img[e] = s < 0 ? 0.f : ldexpf(canon[s], (int)shift[e]);
 }
 
+int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream) {
+  NF_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, stream, g, n,
+                     flag);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                long long step, hipStream_t stream) {
+                long long step, hipStream_t stream, const int* skip) {
   const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2,
-                     eps, c1, c2);
+                     eps, c1, c2, skip);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
 
-int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream) {
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, n, lr);
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip) {
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, n, lr, skip);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

@@ -131,6 +131,10 @@ struct nf_flow {
   std::vector<int> pad_map;    // caller's index -> padded index
   int* d_pad_map = nullptr;
   float* d_pad_tmp = nullptr;  // [user_count]
+  // option "skip_nonfinite_updates" (optax.apply_if_finite): a step whose gradient holds a NaN or an infinity
+  // leaves weights and optimiser moments as they are
+  bool skip_nonfinite = false;
+  int* d_skip_flag = nullptr;
   float* d_wimg = nullptr;  // path-specific packed weights
   // PATH_AFFINE2D_H64 with nf_flow_set_option("hidden_matmul", "bf16x3"): a second image, rebuilt
   // lazily from the canonical weights whenever they changed
@@ -541,6 +545,7 @@ void nf_flow_destroy(nf_flow* f) {
   if (f->h_reduce) hipHostFree(f->h_reduce);
   hipFree(f->d_pad_map);
   hipFree(f->d_pad_tmp);
+  hipFree(f->d_skip_flag);
   if (f->ev0) hipEventDestroy(f->ev0);
   if (f->ev1) hipEventDestroy(f->ev1);
   if (f->stream) hipStreamDestroy(f->stream);
@@ -652,6 +657,14 @@ int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
               path_name(PATH_AFFINE2D_H64), path_name(PATH_RQS2D_H64), path_name(PATH_GENERIC), path_name(f->path));
     return NF_ERR_UNSUPPORTED;
   }
+  if (strcmp(name, "skip_nonfinite_updates") == 0) {
+    if (strcmp(value, "0") != 0 && strcmp(value, "1") != 0) {
+      set_error("skip_nonfinite_updates: unknown value '%s' (0, 1)", value);
+      return NF_ERR_INVALID;
+    }
+    f->skip_nonfinite = value[0] == '1';
+    return NF_OK;
+  }
   set_error("unknown option '%s'", name);
   return NF_ERR_INVALID;
 }
@@ -661,6 +674,10 @@ int nf_flow_get_option(const nf_flow* f, const char* name, char* buf, size_t buf
   if (strcmp(name, "hidden_matmul") == 0) {
     const bool on = f->path == PATH_GENERIC ? f->plan.x3 : f->x3;
     snprintf(buf, buf_len, "%s", on ? "bf16x3" : "f32");
+    return NF_OK;
+  }
+  if (strcmp(name, "skip_nonfinite_updates") == 0) {
+    snprintf(buf, buf_len, "%s", f->skip_nonfinite ? "1" : "0");
     return NF_OK;
   }
   set_error("unknown option '%s'", name);
@@ -1179,11 +1196,17 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
   NF_TRY(enqueue_nll_grad(f, x_dev, rows_local, rows_global));
   t.step += 1;
   float* canon = f->path == PATH_SPLIT2D_SMALL ? f->d_wimg : t.d_canon;
+  const int* skip = nullptr;
+  if (f->skip_nonfinite) {
+    if (!f->d_skip_flag) NF_HIP(hipMalloc(&f->d_skip_flag, sizeof(int)));
+    NF_TRY(launch_nonfinite_flag(t.d_grad, f->weight_count, f->d_skip_flag, f->stream));
+    skip = f->d_skip_flag;
+  }
   if (opt->kind == NF_OPT_ADAM)
     NF_TRY(launch_adam(canon, t.d_grad, t.d_m, t.d_v, f->weight_count, opt->learning_rate, opt->beta1, opt->beta2,
-                       opt->eps, t.step, f->stream));
+                       opt->eps, t.step, f->stream, skip));
   else
-    NF_TRY(launch_sgd(canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream));
+    NF_TRY(launch_sgd(canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream, skip));
   if (f->path == PATH_AFFINE2D_H64) {
     NF_TRY(launch_repack(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg,
                          (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));

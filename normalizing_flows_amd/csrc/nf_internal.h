@@ -120,8 +120,9 @@ int launch_gather(const float* partials, int nparts, const int* map, const float
                   long long rows_global, hipStream_t stream);
 }  // namespace affine2d_bwd
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                long long step, hipStream_t stream);
-int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream);
+                long long step, hipStream_t stream, const int* skip = nullptr);  // *skip != 0: leave everything as it is
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip = nullptr);
+int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream);  // *flag = any NaN / inf in g
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
                   hipStream_t stream);
 

@@ -29,6 +29,13 @@ def sgd(learning_rate: float) -> _lib.Optimizer:
     return _lib.Optimizer(kind=_lib.OPT_SGD, learning_rate=learning_rate, beta1=0.0, beta2=0.0, eps=0.0)
 
 
+def apply_if_finite(model: Transformed, enable: bool = True) -> None:
+    """optax.apply_if_finite around the optimiser: a step whose gradient holds a NaN or an infinity (one far outlier
+    in a batch is enough for an unconstrained exp(log_scale) flow in float32) leaves weights and moments untouched
+    instead of turning every weight into NaN.  The reference's scripts do not wrap their optimiser; off by default."""
+    model.set_option("skip_nonfinite_updates", "1" if enable else "0")
+
+
 def _flow_of(model: Transformed):
     flow, direction = model._lowered()
     if direction != _lib.DIR_CHAIN_FORWARD:

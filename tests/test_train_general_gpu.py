@@ -352,3 +352,35 @@ def test_padded_narrow_flow_trains_in_the_callers_layout(nfa, kind):
     w_before = _flat(f.get_weights())
     f.train_step(x, training.sgd(0.01))
     assert np.abs(_flat(f.get_weights()) - (w_before - 0.01 * _flat(g_before))).max() <= 1e-6
+
+
+@pytest.mark.parametrize("kind", ["affine_fused", "rqs_general"])
+def test_skip_nonfinite_updates(nfa, kind):
+    """Option "skip_nonfinite_updates" (optax.apply_if_finite): a batch whose loss overflows float32 leaves weights
+    and optimiser moments untouched; without it the step makes every weight NaN, which is what the reference's
+    unwrapped optax.adam does with a non-finite gradient."""
+    from normalizing_flows_amd import training
+    if kind == "affine_fused":
+        spec = O.make_affine_spec(4, final_std=0.05)
+        make = lambda: affine_flow(nfa, spec)
+    else:
+        spec = O.make_rqs_spec(3, event_size=4, hidden=(32, 32), num_bins=8, range_min=-4.0, range_max=4.0, final_std=0.05)
+        make = lambda: rqs_flow(nfa, spec)
+    D = spec.event_size
+    good = (np.random.default_rng(3).standard_normal((256, D)) * 1.5).astype(np.float32)
+    bad = good.copy()
+    bad[17, 0] = 3e38   # the base density's square overflows
+    opt = training.adam(1e-3)
+    f = make()
+    f.set_option("skip_nonfinite_updates", "1")
+    assert f.get_option("skip_nonfinite_updates") == "1"
+    w0 = _flat(f.get_weights())
+    loss = f.train_step(bad, opt)
+    assert not np.isfinite(loss)
+    assert np.array_equal(_flat(f.get_weights()), w0)
+    loss = f.train_step(good, opt)
+    w1 = _flat(f.get_weights())
+    assert np.isfinite(loss) and np.isfinite(w1).all() and np.abs(w1 - w0).max() > 1e-4
+    g = make()
+    g.train_step(bad, opt)
+    assert not np.isfinite(_flat(g.get_weights())).all()
