@@ -274,14 +274,19 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
   }
 }
 
-// grad[q] += sum over workgroups (in order) of partial[b][q], q < span
+// grad[q] += sum over workgroups of partial[b][q], q < span: 64 outputs per workgroup, its four waves each add
+// every fourth slab in order, LDS joins the four sums in a fixed order
 __global__ __launch_bounds__(256) void small_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int span,
                                                                float* __restrict__ grad) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= span) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * span + q];
-  grad[q] += s;
+  if (q < span)
+    for (int b = grp; b < nblocks; b += 4) s += partial[(size_t)b * span + q];
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && q < span) grad[q] += ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 bool mlp_small_bwd_applicable(const Linear* Ls, int nlin, int D) {
@@ -338,7 +343,7 @@ int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, co
   else if (nlin == 3) hipLaunchKernelGGL(mlp_small_bwd_kernel<3>, dim3(blocks), dim3(256), lds_bytes, stream, a);
   else hipLaunchKernelGGL(mlp_small_bwd_kernel<4>, dim3(blocks), dim3(256), lds_bytes, stream, a);
   if (blocks > 1)
-    hipLaunchKernelGGL(small_bwd_reduce_kernel, dim3((a.span + 255) / 256), dim3(256), 0, stream, partial, blocks, a.span,
+    hipLaunchKernelGGL(small_bwd_reduce_kernel, dim3((a.span + 63) / 64), dim3(256), 0, stream, partial, blocks, a.span,
                        grad + lo);
   NF_HIP(hipGetLastError());
   return NF_OK;
