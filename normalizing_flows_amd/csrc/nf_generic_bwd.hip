@@ -287,15 +287,15 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void rqs_masked_bwd_kernel(const float* __restrict__ v, float* __restrict__ G,
                                                              const float* __restrict__ th, float* __restrict__ dth,
                                                              long long rows, int D, int pass_parity, float gld,
-                                                             RqsConst c) {
+                                                             int ipp, RqsConst c) {
   extern __shared__ __attribute__((aligned(16))) float sm_bwd[];
   const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
   const int P = 3 * c.K + 1;
   const long long total = rows * Dt;
-  float* sp = sm_bwd;             // [256][P] parameters
-  float* sg = sm_bwd + 256 * P;   // [256][P] their gradient
-  for (long long q0 = (long long)blockIdx.x * 256; q0 < total; q0 += (long long)gridDim.x * 256) {
-    const int items = (int)(total - q0 < 256 ? total - q0 : 256);
+  float* sp = sm_bwd;             // [ipp][P] parameters (ipp <= 256 items per pass: what fits the LDS)
+  float* sg = sm_bwd + ipp * P;   // [ipp][P] their gradient
+  for (long long q0 = (long long)blockIdx.x * ipp; q0 < total; q0 += (long long)gridDim.x * ipp) {
+    const int items = (int)(total - q0 < ipp ? total - q0 : ipp);
     const int nfl = items * P;
     const float* src = th + (size_t)q0 * P;
     for (int e = threadIdx.x; e < nfl; e += 256) sp[e] = src[e];
@@ -571,20 +571,22 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
                            par, gld);
       } else {
         const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
-        const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(4096, (n * Dt + 255) / 256)));
-        const size_t lds = (size_t)2 * 256 * (3 * rc.K + 1) * sizeof(float);  // K = 32: 99 KB
+        const int P = 3 * rc.K + 1;
+        const int ipp = std::min<int>(256, (int)((size_t)150 * 1024 / ((size_t)2 * P * sizeof(float))));  // K = 32: 197
+        const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(4096, (n * Dt + ipp - 1) / ipp)));
+        const size_t lds = (size_t)2 * ipp * P * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           attr_set = true;
         }
-        if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
-        else hipLaunchKernelGGL((rqs_masked_bwd_kernel<32>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, rc);
+        if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
+        else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
+        else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
+        else hipLaunchKernelGGL((rqs_masked_bwd_kernel<32>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
       }
       NF_HIP(hipGetLastError());
       // 4. MLP backward

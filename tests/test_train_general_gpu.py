@@ -384,3 +384,13 @@ def test_skip_nonfinite_updates(nfa, kind):
     g = make()
     g.train_step(bad, opt)
     assert not np.isfinite(_flat(g.get_weights())).all()
+
+
+@pytest.mark.parametrize("K", [21, 32])
+def test_spline_gradient_many_bins(nfa, K):
+    """Largest bin counts of the general backward (K <= 32): the spline's backward kernel stages 3K+1 parameters and
+    their gradient per item through LDS and takes fewer items per pass when 256 would not fit."""
+    spec = O.make_rqs_spec(2, event_size=3, hidden=(24,), num_bins=K, range_min=-4.0, range_max=4.0, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    x = (np.random.default_rng(K).standard_normal((700, 3)) * 1.5).astype(np.float32)
+    check_grads(f, spec, x)
