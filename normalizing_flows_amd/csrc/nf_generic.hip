@@ -238,6 +238,79 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
     }
 }
 
+// Small batches (the reference trains at batch 128): a [128 x N] result has N / 128 tiles -- four workgroups
+// for N = 512 -- and each walks the whole K alone (307 k tiles for the MNIST shape's d theta W^T: 0.6 ms on 4 of 256
+// CUs).  Split K: workgroup (tile, s) multiplies the k range [s Kc, (s+1) Kc) and writes its raw tile to
+// partial[s][M][N]; gemm_splitk_reduce_kernel adds the S slabs in order (run-to-run identical) and applies bias
+// and activation.
+__global__ __launch_bounds__(256, 4) void gemm_splitk_kernel(const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ W, float* __restrict__ partial,
+                                                             int M, int N, int K, int Kc, int gx, int gy) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x % (gx * gy), s = blockIdx.x / (gx * gy);
+  const int m0 = (tile / gx) * FBM, n0 = (tile % gx) * FBN;
+  const int k0 = s * Kc;
+  f32x16 acc[2][2];
+  gemm_fast_mainloop(A + k0, lda, W + (size_t)k0 * N, M, N, min(Kc, K - k0), m0, n0, smem, acc);
+  float* out = partial + (size_t)s * M * N;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + i;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (row < M) out[(size_t)row * N + col] = acc[t][u][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int S,
+                                                                 const float* __restrict__ bias, float* __restrict__ Cm,
+                                                                 int ldc, int M, int N, int act,
+                                                                 const float* __restrict__ aux) {
+  const size_t total = (size_t)M * N;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    const int row = (int)(q / N), col = (int)(q - (size_t)row * N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += partial[(size_t)s * total + q];
+    v += bias[col];
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+    else if (act >= 3) v = aux[(size_t)row * ldc + col] > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
+    Cm[(size_t)row * ldc + col] = v;
+  }
+}
+
+// grow-only scratch for the split-K slabs, one per (host thread, stream): handles are driven from one thread each,
+// and two handles of one thread run on different streams
+static float* splitk_scratch(hipStream_t stream, size_t floats) {
+  struct Slot { hipStream_t stream; float* ptr; size_t floats; };
+  static thread_local std::vector<Slot> slots;
+  for (Slot& sl : slots)
+    if (sl.stream == stream) {
+      if (sl.floats >= floats) return sl.ptr;
+      hipStreamSynchronize(stream);
+      hipFree(sl.ptr);
+      sl.ptr = nullptr;
+      sl.floats = 0;
+      if (hipMalloc(&sl.ptr, floats * sizeof(float)) != hipSuccess) return nullptr;
+      sl.floats = floats;
+      return sl.ptr;
+    }
+  Slot sl{stream, nullptr, 0};
+  if (hipMalloc(&sl.ptr, floats * sizeof(float)) != hipSuccess) return nullptr;
+  sl.floats = floats;
+  slots.push_back(sl);
+  return sl.ptr;
+}
+
 // act: 0 none, 1 relu, 2 leaky_relu; 3 / 4: the backward forms -- the result is multiplied by
 // relu' / leaky_relu' of `aux` (an activation OUTPUT of the same shape and leading dimension as C)
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
@@ -252,6 +325,28 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
       attr_set = true;
     }
     const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
+    // few tiles and a long K: split K over enough workgroups to fill the chip (>= 4 k tiles each)
+    const int tiles = gx * gy, ktiles = (K + FBK - 1) / FBK;
+    if (tiles <= 64 && ktiles >= 8 && getenv("NF_NO_SPLITK") == nullptr) {
+      static bool attr2 = false;
+      if (!attr2) {
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitk_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr2 = true;
+      }
+      int S = std::min((512 + tiles - 1) / tiles, ktiles / 4);
+      const int Kc = ((ktiles + S - 1) / S) * FBK;
+      S = (K + Kc - 1) / Kc;
+      float* partial = splitk_scratch(stream, (size_t)S * M * N);
+      if (partial == nullptr) { set_error("out of device memory for the split-K slabs"); return NF_ERR_HIP; }
+      hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * S), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
+                         W, partial, M, N, K, Kc, gx, gy);
+      const size_t total = (size_t)M * N;
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256),
+                         0, stream, partial, S, bias, Cm, ldc, M, N, act, aux);
+      NF_HIP(hipGetLastError());
+      return NF_OK;
+    }
     hipLaunchKernelGGL(gemm_fast_kernel, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
                        W, bias, Cm, ldc, M, N, K, act, gx, gy, aux);
     NF_HIP(hipGetLastError());
