@@ -701,8 +701,53 @@ __global__ __launch_bounds__(256) void base_log_prob_kernel(const float* __restr
   }
 }
 
+// Wide events (D >= 64, the image flows): one wave per row -- coalesced reads, lane sums in a fixed order -- instead of
+// one thread walking its row alone (lanes 3 KB apart at D = 784: 122 us for 128 rows).
+__global__ __launch_bounds__(256) void base_log_prob_wide_kernel(const float* __restrict__ z, const float* __restrict__ ld,
+                                                                float* __restrict__ lp, double* __restrict__ block_sums,
+                                                                long long rows, int D, int base) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double sum = 0.0;  // lane 0 of each wave carries its rows
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float* v = z + row * D;
+    float out;
+    if (base == NF_BASE_STD_NORMAL) {
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss = fmaf(v[d], v[d], ss);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
+      out = -0.5f * ss - (float)D * 0.9189385332046727f;
+    } else {
+      int bad = 0;
+      for (int d = lane; d < D; d += 64) bad |= !(v[d] >= 0.f && v[d] <= 1.f);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) bad |= __shfl_down(bad, off);
+      out = bad ? -INFINITY : 0.f;
+    }
+    if (lane == 0) {
+      if (ld) out += ld[row];
+      if (lp) lp[row] = out;
+      sum += (double)out;
+    }
+  }
+  if (block_sums) {
+    __shared__ double red[4];
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
 int launch_base_log_prob(const float* z, const float* ld, float* lp, double* block_sums, long long rows,
                          int D, int base, hipStream_t stream, int* out_grid) {
+  if (D >= 64) {
+    long long want = (rows + 3) / 4;
+    const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    if (out_grid) *out_grid = grid;
+    hipLaunchKernelGGL(base_log_prob_wide_kernel, dim3(grid), dim3(256), 0, stream, z, ld, lp, block_sums, rows, D, base);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   long long want = (rows + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   if (out_grid) *out_grid = grid;
