@@ -1192,7 +1192,11 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
         if (record_tape)  // training: every Linear's output stays (hidden activations and theta)
           dst = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * L.N;
-        if (x3 && d_wx3 && gemm_x3_applicable(a, lda, L.N, L.K))
+        // bf16x3 mode: grids of a few tiles (small batches) take the float32 GEMM, which splits K over the chip
+        // (the same test as launch_gemm's)
+        const bool few_tiles = (long long)((L.N + 127) / 128) * ((n + 127) / 128) <= 64 && L.K >= 8 * 32 &&
+                               getenv("NF_NO_SPLITK") == nullptr;
+        if (x3 && d_wx3 && !few_tiles && gemm_x3_applicable(a, lda, L.N, L.K))
           NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
                                 j == nlin - 1 ? 0 : act, stream));
         else
