@@ -650,6 +650,15 @@ int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
     if (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64) { f->x3 = on; return NF_OK; }
     if (f->path == PATH_GENERIC) {
       NF_HIP(hipStreamSynchronize(f->stream));
+      if (on && f->train.ready && f->train.step > 0) {
+        // the split images are packed on the host: after optimiser steps on the device the plan is rebuilt from
+        // the trained weights (its own host copy still holds the ones it was built with)
+        std::vector<float> w(f->weight_count);
+        NF_TRY(::get_weights_internal(f, w.data(), w.size()));
+        f->plan.x3 = true;
+        NF_TRY(f->plan.build(f->desc, w.data()));
+        return f->plan.prepare_backward();
+      }
       return f->plan.set_x3(on);
     }
     if (!on) return NF_OK;

@@ -989,6 +989,7 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
       k5_layer_floats = (size_t)(last.K + 1) * k5_npad;
       NF_HIP(hipMalloc(&d_wk5, k5_layer_floats * d.num_layers * sizeof(float)));
       k5 = true;
+      k5_stale = false;
       NF_TRY(refresh_k5(nullptr));
       NF_HIP(hipDeviceSynchronize());
     }
@@ -1133,6 +1134,10 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
   const int nlin = d.num_hidden + 1;
   const int nlay = io.layer_end - io.layer_begin;
   NF_TRY(ensure_scratch(io.rows));
+  if (k5 && k5_stale && !record_tape) {
+    NF_TRY(refresh_k5(stream));
+    k5_stale = false;
+  }
   const int act = d.activation == NF_ACT_RELU ? 1 : 2;
   const RqsConst rc = make_rqs_const(d);
   for (long long r0 = 0; r0 < io.rows; r0 += scratch_rows) {

@@ -489,7 +489,8 @@ int Plan::refresh_from_canonical(const float* d_canon, hipStream_t stream) {
   hipLaunchKernelGGL(transpose_all_kernel, dim3(b.transpose_blocks, (unsigned)linears.size()), dim3(256), 0, stream,
                      d_weights, b.d_wT, static_cast<const TransposeJob*>(b.d_jobs));
   NF_HIP(hipGetLastError());
-  return refresh_k5(stream);
+  k5_stale = true;  // the training walk does not use the fused last Linear: re-laid when an evaluation asks for it
+  return NF_OK;
 }
 
 int Plan::ensure_tape(long long rows) {

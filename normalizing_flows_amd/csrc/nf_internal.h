@@ -230,7 +230,8 @@ struct Plan {
   size_t k5_layer_floats = 0;
   int k5_npad = 0;
   std::vector<size_t> k5_x3_off;     // per layer: the K5-layout split image inside d_wx3 (bf16x3 mode)
-  int refresh_k5(hipStream_t stream);  // from d_weights (after build and after every optimiser step)
+  bool k5_stale = false;             // an optimiser step changed d_weights: re-lay before the next fused walk
+  int refresh_k5(hipStream_t stream);  // from d_weights (after build; after optimiser steps on the next evaluation walk)
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
   int prepare_backward();            // after build(): index map, transposes, buffers

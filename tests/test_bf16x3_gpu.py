@@ -364,3 +364,28 @@ def test_x3_fused_affine_backward(nfa, L, parity, rows, density):
         _, rg = O.affine_nll_and_grad(cur, x)
         p, m, v = O.adam_reference(p, _flat(rg), m, v, step, 1e-3)
     assert np.abs(_flat(f.get_weights()) - p).max() <= 0.05 * 2 * 1e-3
+
+
+def test_x3_after_training_in_f32_uses_the_trained_weights(nfa):
+    """General path: the split weight images are built on the host; switching the mode on after optimiser steps
+    that ran on the device must pack the TRAINED weights (and the fused last Linear must follow them too)."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(2, event_size=6, hidden=(96, 128), num_bins=8, range_min=-4.0, range_max=4.0, final_std=0.05)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "generic_gemm"
+    x = (np.random.default_rng(5).standard_normal((700, 6)) * 1.5).astype(np.float32)
+    opt = training.adam(5e-3)
+    for _ in range(3):
+        f.train_step(x, opt)
+    trained = O.make_rqs_spec(2, event_size=6, hidden=(96, 128), num_bins=8, range_min=-4.0, range_max=4.0, final_std=0.05)
+    trained.layers = f.get_weights()
+    ref = O.log_prob(trained, x)
+    assert np.abs(ref - O.log_prob(spec, x)).max() > 1e-2     # the steps did change the density
+    e32 = np.abs(O.log_prob(trained, x, np.float32) - ref).max()
+    assert_close(f.log_prob(x), ref, "f32 after training", 4 * e32)
+    f.set_option("hidden_matmul", "bf16x3")
+    assert_close(f.log_prob(x), ref, "bf16x3 after training in f32", 6 * e32)
+    f.train_step(x, opt)   # and one more step under the mode
+    trained.layers = f.get_weights()
+    ref = O.log_prob(trained, x)
+    assert_close(f.log_prob(x), ref, "bf16x3 after a step under the mode", 6 * np.abs(O.log_prob(trained, x, np.float32) - ref).max())
