@@ -327,7 +327,7 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
     const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
     // few tiles and a long K: split K over enough workgroups to fill the chip (>= 4 k tiles each)
     const int tiles = gx * gy, ktiles = (K + FBK - 1) / FBK;
-    if (tiles <= 64 && ktiles >= 8 && getenv("NF_NO_SPLITK") == nullptr) {
+    if (tiles <= 128 && ktiles >= 8 && getenv("NF_NO_SPLITK") == nullptr) {
       static bool attr2 = false;
       if (!attr2) {
         NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitk_kernel),
@@ -1199,7 +1199,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
           dst = bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * L.N;
         // bf16x3 mode: grids of a few tiles (small batches) take the float32 GEMM, which splits K over the chip
         // (the same test as launch_gemm's)
-        const bool few_tiles = (long long)((L.N + 127) / 128) * ((n + 127) / 128) <= 64 && L.K >= 8 * 32 &&
+        const bool few_tiles = (long long)((L.N + 127) / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
                                getenv("NF_NO_SPLITK") == nullptr;
         if (x3 && d_wx3 && !few_tiles && gemm_x3_applicable(a, lda, L.N, L.K))
           NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
