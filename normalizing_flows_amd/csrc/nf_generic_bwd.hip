@@ -55,13 +55,29 @@ struct TransposeJob {
 };
 __global__ __launch_bounds__(256) void transpose_all_kernel(const float* __restrict__ weights, float* __restrict__ wT,
                                                             const TransposeJob* __restrict__ jobs) {
+  // 32 x 32 tiles through LDS: reads run along n, writes along k (the element-wise form read with stride N:
+  // 0.7 TB/s on the MNIST shape's 351 MB)
+  __shared__ float tile[32][33];
   const TransposeJob job = jobs[blockIdx.y];
-  const long long total = (long long)job.K * job.N;
+  const int K = job.K, N = job.N;
   const float* W = weights + job.w_off;
   float* WT = wT + job.wT_off;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-    const int n = (int)(q / job.K), k = (int)(q % job.K);
-    WT[q] = W[(size_t)k * job.N + n];
+  const int tk = (K + 31) / 32, tn = (N + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (long long t = blockIdx.x; t < (long long)tk * tn; t += gridDim.x) {
+    const int k0 = (int)(t / tn) * 32, n0 = (int)(t % tn) * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + ty + 8 * r, n = n0 + tx;
+      tile[ty + 8 * r][tx] = (k < K && n < N) ? W[(size_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + ty + 8 * r, k = k0 + tx;
+      if (n < N && k < K) WT[(size_t)n * K + k] = tile[tx][ty + 8 * r];
+    }
+    __syncthreads();
   }
 }
 
