@@ -1173,7 +1173,11 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       } else
       for (int j = 0; j < nlin; ++j) {
         const Linear& L = linears[(size_t)l * nlin + j];
-        if (j == nlin - 1 && k5 && !record_tape && (lda & 3) == 0 &&
+        // (a batch of one or two row blocks leaves the fused kernel ~80 workgroups that each walk the whole K; the
+        // split-K GEMM + the transform kernel are quicker there: 45 -> 32 us per layer at the MNIST shape, batch 128)
+        const bool k5_small = (long long)(k5_npad / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
+                              getenv("NF_NO_SPLITK") == nullptr;
+        if (j == nlin - 1 && k5 && !k5_small && !record_tape && (lda & 3) == 0 &&
             (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
           // K5: GEMM + spline in one kernel; theta stays in LDS
           const float* wk = d_wk5 + (size_t)l * k5_layer_floats;

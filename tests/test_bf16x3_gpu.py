@@ -211,9 +211,12 @@ def test_x3_generic_rqs(nfa):
     assert_close(f.log_prob(x), O.log_prob(spec, x), "rqs D=6 bf16x3")
 
 
-def test_x3_mnist_shape(nfa):
+@pytest.mark.parametrize("small_batch_form", [True, False])
+def test_x3_mnist_shape(nfa, monkeypatch, small_batch_form):
     """BASELINE.json configs[4] shapes under the option; the two statements of
     tests/test_parity_gpu.py::test_rqs_mnist_shape_config5."""
+    if not small_batch_form:
+        monkeypatch.setenv("NF_NO_SPLITK", "1")  # the large-batch kernels (gemm_x3, fused spline epilogue) on 96 rows
     x = O.make_inputs("mnist_like", 96)
     spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0,
                            range_max=1.0, base="uniform01", final_std=0.2)

@@ -453,8 +453,12 @@ def test_rqs_other_event_sizes(nfa, D, hidden, K, L):
     assert_close(f.log_prob(x), O.log_prob(spec, x), "rqs D")
 
 
-def test_rqs_mnist_shape_config5(nfa):
-    """BASELINE.json configs[4] shapes (784-D, MLP 512x3, K=8 on [0,1], Uniform base) at a
+@pytest.mark.parametrize("small_batch_form", [True, False])
+def test_rqs_mnist_shape_config5(nfa, monkeypatch, small_batch_form):
+    """(small_batch_form False: NF_NO_SPLITK keeps the kernels of large batches -- the GEMMs that walk K whole and the
+    spline in the last GEMM's epilogue -- on these 96 rows; True: split-K GEMMs and the separate transform kernel, what
+    a batch this small gets by default.)
+    BASELINE.json configs[4] shapes (784-D, MLP 512x3, K=8 on [0,1], Uniform base) at a
     size the oracle finishes: 2 layers, 96 rows.
 
     A 784-D log_prob is a sum of 392 * L per-pixel log-dets, so float32 rounding
@@ -463,6 +467,8 @@ def test_rqs_mnist_shape_config5(nfa):
       (i)  |log_prob| ~ 1e2 (final_std 0.2): 1e-5 relative, the tolerance of every test here;
       (ii) near-identity flow (|log_prob| ~ 1): no further from float64 than twice the
            float32 restatement is (as exact as the reference's arithmetic type allows)."""
+    if not small_batch_form:
+        monkeypatch.setenv("NF_NO_SPLITK", "1")
     x = O.make_inputs("mnist_like", 96)
     spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0,
                            range_max=1.0, base="uniform01", final_std=0.2)
@@ -612,6 +618,7 @@ def test_rqs_spline_in_gemm_epilogue(nfa, monkeypatch, mode, K, D, hidden, L, ro
     (`std` of the last Linear is small for the 64-D / 256-wide cases: at 0.08 that flow's inverse is
     ill-conditioned -- float32 NumPy, the unfused path and this kernel all land 3 units away from float64.)"""
     from normalizing_flows_amd import _lib
+    monkeypatch.setenv("NF_NO_SPLITK", "1")  # tiny batches with K >= 256 would otherwise take the unfused small-batch form
     spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=-5.0, range_max=5.0,
                            final_std=std, first_parity=parity)
     x = (np.random.default_rng(K * 100 + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
