@@ -683,6 +683,31 @@ def test_narrow_2d_flows_run_on_the_fused_kernels(nfa, mode, kind, hidden, K):
             assert np.array_equal(got[l][j][1], np.asarray(spec.layers[l][j][1], np.float32))
 
 
+@pytest.mark.parametrize("kind,D,hidden,rows", [("affine", 12, (256, 320), 1), ("affine", 12, (256, 320), 1000),
+                                                ("rqs", 40, (288, 260), 333), ("rqs", 9, (512,), 129)])
+def test_general_path_small_batches_split_k(nfa, monkeypatch, kind, D, hidden, rows):
+    """General path at small batches: GEMMs whose grid has few tiles split K over the chip (ragged last split, K not a
+    multiple of 32, one to eight row blocks) and the spline layers' last Linear runs unfused -- against the oracle, and
+    against the same flow with NF_NO_SPLITK (the large-batch kernels on the same rows)."""
+    if kind == "affine":
+        spec = O.make_affine_spec(3, event_size=D, hidden=hidden, final_std=0.03)
+        make = lambda: affine_flow(nfa, spec)
+    else:
+        spec = O.make_rqs_spec(3, event_size=D, hidden=hidden, num_bins=8, range_min=-4.0, range_max=4.0, final_std=0.05)
+        make = lambda: rqs_flow(nfa, spec)
+    x = (np.random.default_rng(D + rows).standard_normal((rows, D)) * 1.5).astype(np.float32)
+    ref = O.log_prob(spec, x)
+    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    f = make()
+    assert f.kernel_name == "generic_gemm"
+    got = f.log_prob(x)
+    assert_close(got, ref, "split-K log_prob", FLOOR * e32)
+    monkeypatch.setenv("NF_NO_SPLITK", "1")
+    whole = make().log_prob(x)
+    assert_close(whole, ref, "whole-K log_prob", FLOOR * e32)
+    assert np.abs(whole.astype(np.float64) - got).max() <= 2 * max(FLOOR * e32, float(tol(ref).max()))
+
+
 # ------------------------------------------------------------------ backward pass / training step
 def _flat(layers):
     return np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()])
