@@ -1110,8 +1110,15 @@ int launch_transform(const nf_flow_desc& d, float* yc, float* ldc, const float* 
   } else {
     bool done = false;
     if (getenv("NF_RQS_SIMPLE") == nullptr) {
-      if (rc.K == 8) done = launch_rqs_rows<8>(yc, ldc, params, n, D, par, inverse_op, rc, stream);
-      else if (rc.K == 12) done = launch_rqs_rows<12>(yc, ldc, params, n, D, par, inverse_op, rc, stream);
+      switch (rc.K) {  // the bin counts the register form is built for; others take the run-time-K kernel below
+        case 4: done = launch_rqs_rows<4>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        case 6: done = launch_rqs_rows<6>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        case 8: done = launch_rqs_rows<8>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        case 10: done = launch_rqs_rows<10>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        case 12: done = launch_rqs_rows<12>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        case 16: done = launch_rqs_rows<16>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
+        default: break;
+      }
     }
     if (!done) {
       const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
