@@ -13,9 +13,13 @@ def free_mem():
     hip.hipMemGetInfo(C.byref(a), C.byref(b))
     return a.value
 specs = [("affine", O.make_affine_spec(4, final_std=0.02)), ("rqs", O.make_rqs_spec(3, final_std=0.05)),
-         ("gen", O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03))]
+         ("gen", O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03)),
+         ("pad", O.make_affine_spec(4, hidden=(50, 50), final_std=0.02)),          # zero-padded onto the fused kernel
+         ("narrow", O.make_affine_spec(2, event_size=6, hidden=(32, 48), final_std=0.03)),  # one-launch backward
+         ("wide", O.make_affine_spec(2, event_size=8, hidden=(512, 256), final_std=0.03))]  # split-K GEMMs
 x2 = O.make_inputs("banana", 4096)
 x8 = np.random.default_rng(0).standard_normal((4096, 8)).astype(np.float32)
+x6 = np.random.default_rng(1).standard_normal((4096, 6)).astype(np.float32)
 base = None
 for it in range(60):
     for kind, spec in specs:
@@ -24,9 +28,10 @@ for it in range(60):
         else:
             cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=spec.event_size, num_layers=len(spec.layers), hidden=tuple(w.shape[1] for w, _ in spec.layers[0][:-1]))
         f = nfa.CouplingFlow(cfg, spec.layers)
-        x = x8 if kind == "gen" else x2
+        x = x8 if kind in ("gen", "wide") else (x6 if kind == "narrow" else x2)
         f.log_prob(x); f.nll(x)
         f.set_option("hidden_matmul", "bf16x3"); f.log_prob(x)
+        f.set_option("skip_nonfinite_updates", "1")
         f.train_step(x, training.adam(1e-4))
         f.log_prob(x)
         f.close()
