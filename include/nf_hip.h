@@ -277,11 +277,23 @@ int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev);
    libnf_hip.so.  id is an ncclUniqueId (128 bytes) made on rank 0 and handed to
    the other ranks by the host (bench.py uses torch.distributed's store). */
 #define NF_COMM_ID_BYTES 128
+/* What every rank checks BEFORE any rank enters nf_comm_init_rank: a usable HIP device is current and
+   librccl loads with the symbols used here.  ncclCommInitRank blocks until every rank has entered it, so a
+   rank that cannot get that far must be found first: the host exchanges the results of this call over its
+   own (CPU) channel and all ranks give up together (normalizing_flows_amd/sharding.py: agree_all). */
+int nf_comm_preflight(void);
 int nf_comm_unique_id(unsigned char id[NF_COMM_ID_BYTES]);
 int nf_comm_init_rank(nf_comm** out_comm, int world_size, int rank,
                       const unsigned char id[NF_COMM_ID_BYTES]);
 int nf_comm_destroy(nf_comm* comm);
 int nf_flow_attach_comm(nf_flow* flow, nf_comm* comm); /* NULL detaches */
+/* Number of collectives (NLL-sum and gradient all-reduces) this handle has issued so far.  With a
+   communicator attached nf_nll, nf_nll_result, nf_flow_synchronize, nf_nll_grad and nf_train_step are
+   collective calls: one rank skipping one of them leaves the others waiting inside RCCL.  Ranks that
+   exchange this count over their host channel at a point where it must agree (bench.py does after the
+   timed region) turn such a program error into a message instead of a hang at the NEXT collective.
+   The mean these collectives implement: src/real_nvp_toy_densities.py:143,150. */
+int nf_flow_collective_count(const nf_flow* flow, uint64_t* out_count);
 
 #ifdef __cplusplus
 }

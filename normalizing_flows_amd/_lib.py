@@ -111,10 +111,12 @@ PROTOTYPES = {
     "nf_timer_start": (C.c_int, [C.c_void_p]),
     "nf_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "nf_debug_read_f2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "nf_comm_preflight": (C.c_int, []),
     "nf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "nf_comm_init_rank": (C.c_int, [_void_pp, C.c_int, C.c_int, C.c_void_p]),
     "nf_comm_destroy": (C.c_int, [C.c_void_p]),
     "nf_flow_attach_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nf_flow_collective_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 _LIB: Optional[C.CDLL] = None

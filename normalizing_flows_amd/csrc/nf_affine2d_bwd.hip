@@ -559,8 +559,41 @@ int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t strea
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
+// With a skip flag (option "skip_nonfinite_updates" = optax.apply_if_finite) the step count that enters the bias
+// correction lives on the device and advances only when the update is applied, as the wrapped optimiser's own
+// count does: bias[0..1] = (1 - b1^t, 1 - b2^t), bias[2] = t.
+__global__ void adam_bias_kernel(float* __restrict__ bias, const int* __restrict__ skip, float b1, float b2) {
+  if (*skip != 0) return;
+  const float t = bias[2] + 1.f;
+  bias[2] = t;
+  bias[0] = 1.f - powf(b1, t);
+  bias[1] = 1.f - powf(b2, t);
+}
+__global__ __launch_bounds__(256) void adam_dev_bias_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                            float lr, float b1, float b2, float eps,
+                                                            const float* __restrict__ bias,
+                                                            const int* __restrict__ skip) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n || *skip != 0) return;
+  const float c1 = bias[0], c2 = bias[1];
+  const float ge = g[e];
+  const float me = b1 * m[e] + (1.f - b1) * ge;
+  const float ve = b2 * v[e] + (1.f - b2) * ge * ge;
+  m[e] = me;
+  v[e] = ve;
+  w[e] -= lr * (me / c1) / (sqrtf(ve / c2) + eps);
+}
+
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                long long step, hipStream_t stream, const int* skip) {
+                long long step, hipStream_t stream, const int* skip, float* dev_bias) {
+  if (skip != nullptr && dev_bias != nullptr) {
+    hipLaunchKernelGGL(adam_bias_kernel, dim3(1), dim3(1), 0, stream, dev_bias, skip, b1, b2);
+    hipLaunchKernelGGL(adam_dev_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr,
+                       b1, b2, eps, dev_bias, skip);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2,
                      eps, c1, c2, skip);

@@ -135,6 +135,7 @@ struct nf_flow {
   // leaves weights and optimiser moments as they are
   bool skip_nonfinite = false;
   int* d_skip_flag = nullptr;
+  float* d_adam_bias = nullptr;  // [3]: (1 - b1^t, 1 - b2^t, t) with t = optimiser steps actually applied
   float* d_wimg = nullptr;  // path-specific packed weights
   // PATH_AFFINE2D_H64 with nf_flow_set_option("hidden_matmul", "bf16x3"): a second image, rebuilt
   // lazily from the canonical weights whenever they changed
@@ -169,6 +170,13 @@ struct nf_flow {
   double* h_ring = nullptr;  // pinned, NF_NLL_SLOTS
   long long ring_rows[NF_NLL_SLOTS];
   nf_comm* comm = nullptr;
+  // Every collective this handle issues goes through flow_allreduce_*: one communicator serves both streams
+  // (NLL sums on `side`, gradients on `stream`), so each collective waits for the previous one's event when
+  // that ran on the other stream -- the order on the wire is the order of the calls on every rank -- and the
+  // count lets ranks cross-check that they issued the same number (nf_flow_collective_count).
+  unsigned long long collectives = 0;
+  hipEvent_t ev_coll = nullptr;
+  hipStream_t coll_stream = nullptr;  // stream of the last collective, nullptr before the first
   // slots whose local sum has not been all-reduced yet (bit per slot), and the staging for the one
   // batched all-reduce that serves them
   unsigned long long reduce_pending = 0;
@@ -342,6 +350,28 @@ __global__ void select_pending_kernel(const double* __restrict__ sums, unsigned 
   if (s < NF_NLL_SLOTS) out[s] = (mask >> s & 1ull) ? sums[s] : 0.0;
 }
 
+static int flow_collective_order(nf_flow* f, hipStream_t stream) {
+  if (!f->ev_coll) NF_HIP(hipEventCreateWithFlags(&f->ev_coll, hipEventDisableTiming));
+  if (f->coll_stream && f->coll_stream != stream) NF_HIP(hipStreamWaitEvent(stream, f->ev_coll, 0));
+  return NF_OK;
+}
+static int flow_collective_done(nf_flow* f, hipStream_t stream) {
+  NF_HIP(hipEventRecord(f->ev_coll, stream));
+  f->coll_stream = stream;
+  f->collectives += 1;
+  return NF_OK;
+}
+static int flow_allreduce_f64(nf_flow* f, double* dev_values, size_t count, hipStream_t stream) {
+  NF_TRY(flow_collective_order(f, stream));
+  NF_TRY(comm_allreduce_sum_f64(f->comm, dev_values, count, stream));
+  return flow_collective_done(f, stream);
+}
+static int flow_allreduce_f32(nf_flow* f, float* dev_values, size_t count, hipStream_t stream) {
+  NF_TRY(flow_collective_order(f, stream));
+  NF_TRY(comm_allreduce_sum_f32(f->comm, dev_values, count, stream));
+  return flow_collective_done(f, stream);
+}
+
 // One all-reduce for every slot that waits for it (side stream, after their sums), then the host copy.
 static int flush_pending_reductions(nf_flow* f) {
   const unsigned long long mask = f->reduce_pending;
@@ -349,7 +379,7 @@ static int flush_pending_reductions(nf_flow* f) {
   if (!f->comm) { set_error("pending reductions without a communicator"); return NF_ERR_STATE; }
   hipLaunchKernelGGL(select_pending_kernel, dim3(1), dim3(64), 0, f->side, f->d_sum, mask, f->d_reduce);
   NF_HIP(hipGetLastError());
-  NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_reduce, NF_NLL_SLOTS, f->side));
+  NF_TRY(flow_allreduce_f64(f, f->d_reduce, NF_NLL_SLOTS, f->side));
   NF_HIP(hipMemcpyAsync(f->h_reduce, f->d_reduce, sizeof(double) * NF_NLL_SLOTS, hipMemcpyDeviceToHost, f->side));
   NF_HIP(hipStreamSynchronize(f->side));
   for (int s = 0; s < NF_NLL_SLOTS; ++s)
@@ -410,10 +440,16 @@ int nf_malloc(void** out_ptr, size_t bytes) {
   return NF_OK;
 }
 int nf_free(void* ptr) { if (ptr) NF_HIP(hipFree(ptr)); return NF_OK; }
+// Handles run on non-blocking streams, which the null stream does not order against: a copy (and the
+// handle-less device-mode calls below) first waits for everything enqueued on the device, so that a result a
+// handle has only enqueued (device in -> device out calls return before the kernel ran) is complete when it is
+// read, and an upload cannot overtake a kernel that still reads the destination.
 int nf_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  NF_HIP(hipDeviceSynchronize());
   NF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return NF_OK;
 }
 int nf_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  NF_HIP(hipDeviceSynchronize());
   NF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return NF_OK;
 }
 
@@ -546,6 +582,8 @@ void nf_flow_destroy(nf_flow* f) {
   hipFree(f->d_pad_map);
   hipFree(f->d_pad_tmp);
   hipFree(f->d_skip_flag);
+  hipFree(f->d_adam_bias);
+  if (f->ev_coll) hipEventDestroy(f->ev_coll);
   if (f->ev0) hipEventDestroy(f->ev0);
   if (f->ev1) hipEventDestroy(f->ev1);
   if (f->stream) hipStreamDestroy(f->stream);
@@ -849,7 +887,9 @@ int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, floa
   if (rows == 0) return NF_OK;
   if (!x || !out) { set_error("x or out is NULL"); return NF_ERR_INVALID; }
   if (mem == NF_MEM_DEVICE) {
+    NF_HIP(hipDeviceSynchronize());  // x may have been produced on a handle's (non-blocking) stream
     NF_TRY(generic::launch_base_log_prob(x, nullptr, out, nullptr, rows, event_dim, base, nullptr, nullptr));
+    NF_HIP(hipStreamSynchronize(nullptr));  // complete on return: the next consumer may be any stream
     return NF_OK;
   }
   float *dx = nullptr, *dl = nullptr;
@@ -873,7 +913,9 @@ int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* 
   if (rows == 0) return NF_OK;
   if (!out) { set_error("out is NULL"); return NF_ERR_INVALID; }
   if (mem == NF_MEM_DEVICE) {
+    NF_HIP(hipDeviceSynchronize());  // `out` may still be read by a kernel on a handle's stream
     NF_TRY(generic::launch_base_sample(out, rows, event_dim, base, seed, nullptr));
+    NF_HIP(hipStreamSynchronize(nullptr));
     return NF_OK;
   }
   float* d = nullptr;
@@ -893,7 +935,10 @@ int nf_density_sample(int density, uint64_t seed, int64_t rows, float* out, int 
   if (!out) { set_error("out is NULL"); return NF_ERR_INVALID; }
   if (mem == NF_MEM_DEVICE) {
     NF_TRY(check_device_ptr(out, "out"));
-    return generic::launch_density_sample(out, rows, density, seed, nullptr);
+    NF_HIP(hipDeviceSynchronize());
+    NF_TRY(generic::launch_density_sample(out, rows, density, seed, nullptr));
+    NF_HIP(hipStreamSynchronize(nullptr));
+    return NF_OK;
   }
   float* d = nullptr;
   NF_HIP(hipMalloc(&d, sizeof(float) * rows * 2));
@@ -1013,6 +1058,7 @@ static int ensure_train(nf_flow* f, long long rows) {
     if (f->path == PATH_RQS2D_H64) NF_TRY(f->plan.build(d, f->h_weights.data()));
     NF_TRY(f->plan.prepare_backward());
     t.step = 0;
+    if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     t.ready = true;
   }
   if (!t.ready && split) {
@@ -1024,6 +1070,7 @@ static int ensure_train(nf_flow* f, long long rows) {
     NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
     NF_HIP(hipMalloc(&t.d_partials, (size_t)split2d::bwd_max_blocks() * split2d::layer_floats(d.hidden[0]) * sizeof(float)));
     t.step = 0;
+    if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     t.ready = true;
   }
   if (!t.ready) {
@@ -1057,6 +1104,7 @@ static int ensure_train(nf_flow* f, long long rows) {
     NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
                          (size_t)d.num_layers * affine2d_bwd::kImageFloats, f->stream));
     t.step = 0;
+    if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     t.ready = true;
   }
   if (rows > t.state_rows) {
@@ -1106,7 +1154,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));
   NF_HIP(hipStreamWaitEvent(f->side, f->ev_kernel[slot], 0));
   NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->side));
-  if (f->comm) NF_TRY(comm_allreduce_sum_f64(f->comm, f->d_sum + slot, 1, f->side));
+  if (f->comm) NF_TRY(flow_allreduce_f64(f, f->d_sum + slot, 1, f->side));
   NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->side));
   NF_HIP(hipEventRecord(f->ev_tail[slot], f->side));
   f->tail_pending[slot] = true;
@@ -1115,7 +1163,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   // backward: the layer log_prob applied last (layer 0) first
   if (trains_through_plan(f)) {
     NF_TRY(f->plan.backward(t.d_state_v, t.d_state_g, rows_local, rows_global, t.d_grad, f->weight_count, f->stream));
-    if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+    if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
     return NF_OK;
   }
   if (f->path == PATH_SPLIT2D_SMALL) {
@@ -1124,7 +1172,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
       NF_TRY(split2d::launch_bwd_layer(f->d_wimg + (size_t)l * per, H, d.activation, t.d_state_v, t.d_state_g,
                                        t.d_partials, t.d_grad + (size_t)l * per, rows_local, rows_global,
                                        (l & 1) ^ d.first_mask_parity, l == 0, f->stream));
-    if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+    if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
     return NF_OK;
   }
   const bool bwd_x3 = f->x3;  // the handle's matmul mode covers the backward products that feed other products
@@ -1146,7 +1194,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
     NF_TRY(affine2d_bwd::launch_gather(t.d_partials, nparts, t.d_gmap[cond], t.d_gscale[cond],
                                        t.d_grad + (size_t)l * affine2d_bwd::kCanonFloats, rows_global, f->stream));
   }
-  if (f->comm) NF_TRY(comm_allreduce_sum_f32(f->comm, t.d_grad, f->weight_count, f->stream));
+  if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
   return NF_OK;
 }
 
@@ -1208,12 +1256,19 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
   const int* skip = nullptr;
   if (f->skip_nonfinite) {
     if (!f->d_skip_flag) NF_HIP(hipMalloc(&f->d_skip_flag, sizeof(int)));
+    if (!f->d_adam_bias) {
+      // steps taken so far (all of them applied: the option was off) seed the device-side count
+      const float seed[3] = {0.f, 0.f, (float)(t.step - 1)};
+      NF_HIP(hipMalloc(&f->d_adam_bias, sizeof(seed)));
+      NF_HIP(hipMemcpyAsync(f->d_adam_bias, seed, sizeof(seed), hipMemcpyHostToDevice, f->stream));
+      NF_HIP(hipStreamSynchronize(f->stream));
+    }
     NF_TRY(launch_nonfinite_flag(t.d_grad, f->weight_count, f->d_skip_flag, f->stream));
     skip = f->d_skip_flag;
   }
   if (opt->kind == NF_OPT_ADAM)
     NF_TRY(launch_adam(canon, t.d_grad, t.d_m, t.d_v, f->weight_count, opt->learning_rate, opt->beta1, opt->beta2,
-                       opt->eps, t.step, f->stream, skip));
+                       opt->eps, t.step, f->stream, skip, f->d_adam_bias));
   else
     NF_TRY(launch_sgd(canon, t.d_grad, f->weight_count, opt->learning_rate, f->stream, skip));
   if (f->path == PATH_AFFINE2D_H64) {
@@ -1283,6 +1338,12 @@ int nf_flow_attach_comm(nf_flow* f, nf_comm* comm) {
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   if (f->reduce_pending && f->comm) NF_TRY(flush_pending_reductions(f));  // results owed to the old communicator
   f->comm = comm;
+  return NF_OK;
+}
+
+int nf_flow_collective_count(const nf_flow* f, uint64_t* out_count) {
+  if (!f || !out_count) { set_error("bad argument"); return NF_ERR_INVALID; }
+  *out_count = f->collectives;
   return NF_OK;
 }
 

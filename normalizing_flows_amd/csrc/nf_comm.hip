@@ -97,6 +97,17 @@ int comm_allreduce_sum_f32(nf_comm* c, float* dev_values, size_t count, hipStrea
 
 extern "C" {
 
+int nf_comm_preflight(void) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipFree(nullptr);  // forces the context: a device this process cannot use fails here
+  if (e != hipSuccess) {
+    nf::set_error("no usable HIP device before communicator set-up: %s", hipGetErrorString(e));
+    return NF_ERR_NO_DEVICE;
+  }
+  return load_rccl();
+}
+
 int nf_comm_unique_id(unsigned char id[NF_COMM_ID_BYTES]) {
   if (!id) { nf::set_error("id is NULL"); return NF_ERR_INVALID; }
   NF_TRY(load_rccl());

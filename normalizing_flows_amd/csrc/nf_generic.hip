@@ -414,72 +414,38 @@ __global__ __launch_bounds__(256) void affine_split_kernel(float* __restrict__ y
 }
 
 
-__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
-
-// One (row, transformed dim): spline forward or inverse, returns the new value and log|det|.
-// p points at the 3K+1 raw parameters [widths K | heights K | slopes K+1].
+// One (row, transformed dim), K known only at run time: spline forward or inverse, returns the new value and
+// log|det|.  p points at the 3K+1 raw parameters [widths K | heights K | slopes K+1].  Same arithmetic as the
+// register form (nf_rqs_math.h: float64 bin weights, normalisation and running sums); the bins are walked twice
+// (sums, then knots) instead of being kept.
 __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, const RqsConst& c, float v, int inverse,
                                          float* out, float* logdet) {
   const int K = c.K;
-  const float total = c.range_max - c.range_min;
-  const float scale = total - (float)K * c.min_bin;
   float mw = -INFINITY, mh = -INFINITY;
   for (int k = 0; k < K; ++k) { mw = fmaxf(mw, p[k]); mh = fmaxf(mh, p[K + k]); }
-  float sw = 0.f, sh = 0.f;
-  for (int k = 0; k < K; ++k) { sw += expf(p[k] - mw); sh += expf(p[K + k] - mh); }
-  const float iw = scale / sw, ih = scale / sh;
-  const float s_first = softplus_f(p[2 * K] + c.slope_offset) + c.min_slope;
-  const float s_last = softplus_f(p[3 * K] + c.slope_offset) + c.min_slope;
-  // walk the bins once, keeping the one that contains v (bin 0 when none does)
-  float xl = c.range_min, yl = c.range_min, sl = s_first;
-  float bxl = 0.f, bxr = 0.f, byl = 0.f, byr = 0.f, bsl = 0.f, bsr = 0.f;
-  bool found = false;
+  double sw = 0.0, sh = 0.0;
   for (int k = 0; k < K; ++k) {
-    const float w = expf(p[k] - mw) * iw + c.min_bin;
-    const float hgt = expf(p[K + k] - mh) * ih + c.min_bin;
-    const float xr = k == K - 1 ? c.range_max : xl + w;
-    const float yr = k == K - 1 ? c.range_max : yl + hgt;
-    const float sr = k == K - 1 ? s_last : softplus_f(p[2 * K + k + 1] + c.slope_offset) + c.min_slope;
-    const float lo = inverse ? yl : xl, hi = inverse ? yr : xr;
-    const bool hit = (v >= lo) && (v < hi);
-    if ((hit && !found) || k == 0) { bxl = xl; bxr = xr; byl = yl; byr = yr; bsl = sl; bsr = sr; }
-    found = found || hit;
-    xl = xr; yl = yr; sl = sr;
+    sw += rqsmath::bin_exp<NF_RQS_XEXP>(p[k], mw);
+    sh += rqsmath::bin_exp<NF_RQS_XEXP>(p[K + k], mh);
   }
-  const float bw = bxr - bxl, bh = byr - byl;
-  const float delta = bh / bw;
-  const float st = bsr + bsl - 2.f * delta;
-  float res, ldv;
-  if (!inverse) {
-    float z = (v - bxl) / bw;
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float num = bh * (delta * zz + bsl * z1mz);
-    const float den = delta + st * z1mz;
-    res = byl + num / den;
-    ldv = 2.f * logf(delta) + logf(bsr * zz + 2.f * delta * z1mz + bsl * omz * omz) - 2.f * logf(den);
-    if (v <= c.range_min) { res = (v - c.range_min) * s_first + c.range_min; ldv = logf(s_first); }
-    if (v >= c.range_max) { res = (v - c.range_max) * s_last + c.range_max; ldv = logf(s_last); }
-  } else {
-    float u = (v - byl) / bh;
-    u = fminf(fmaxf(u, 0.f), 1.f);
-    const float qc = -delta * u;
-    const float qb = bsl - st * u;
-    const float qa = delta - qb;
-    float z = -2.f * qc / (qb + sqrtf(qb * qb - 4.f * qa * qc));
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    res = bw * z + bxl;
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float den = delta + st * z1mz;
-    ldv = -2.f * logf(delta) - logf(bsr * zz + 2.f * delta * z1mz + bsl * omz * omz) + 2.f * logf(den);
-    if (v <= c.range_min) { res = (v - c.range_min) / s_first + c.range_min; ldv = -logf(s_first); }
-    if (v >= c.range_max) { res = (v - c.range_max) / s_last + c.range_max; ldv = -logf(s_last); }
+  const double iw = rqsmath::bin_scale(sw, K, c), ih = rqsmath::bin_scale(sh, K, c);
+  const double mb = (double)c.min_bin;
+  // walk the bins once, keeping the last one whose left knot on the search axis is <= v (bin 0 when none is)
+  double ax = (double)c.range_min, ay = (double)c.range_min;
+  float xl = c.range_min, yl = c.range_min;
+  float bxl = 0.f, bxr = 0.f, byl = 0.f, byr = 0.f, raw_l = 0.f, raw_r = 0.f;
+  for (int k = 0; k < K; ++k) {
+    ax += __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[k], mw), iw, mb);
+    ay += __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[K + k], mh), ih, mb);
+    const float xr = k == K - 1 ? c.range_max : (float)ax;
+    const float yr = k == K - 1 ? c.range_max : (float)ay;
+    if (k == 0 || v >= (inverse ? yl : xl)) {
+      bxl = xl; bxr = xr; byl = yl; byr = yr; raw_l = p[2 * K + k]; raw_r = p[2 * K + k + 1];
+    }
+    xl = xr; yl = yr;
   }
-  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
-  // kernels are built with -fno-honor-nans)
-  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
-  *out = v_nan ? v : res;
-  *logdet = v_nan ? v : ldv;
+  if (inverse) rqsmath::rqs_map<1, false>(bxl, bxr, byl, byr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
+  else rqsmath::rqs_map<0, false>(bxl, bxr, byl, byr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
 }
 
 // G lanes (power of two <= 64) share one row: each takes transformed dims dt = sub, sub+G, ...

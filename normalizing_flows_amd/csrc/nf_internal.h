@@ -120,7 +120,8 @@ int launch_gather(const float* partials, int nparts, const int* map, const float
                   long long rows_global, hipStream_t stream);
 }  // namespace affine2d_bwd
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                long long step, hipStream_t stream, const int* skip = nullptr);  // *skip != 0: leave everything as it is
+                long long step, hipStream_t stream, const int* skip = nullptr,  // *skip != 0: leave everything as it is
+                float* dev_bias = nullptr);  // [3] with skip: device-side step count and bias corrections (applied steps only)
 int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip = nullptr);
 int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream);  // *flag = any NaN / inf in g
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
@@ -128,13 +129,23 @@ int launch_repack(const float* canon, const int* src, const signed char* shift, 
 
 // ---- path 1b: masked RQS coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2*(3K+1) ----------
 namespace rqs2d {
-// image of ONE layer (floats); layers are streamed through an LDS double buffer
+// image of ONE layer (floats); layers are streamed through an LDS double buffer.
+// The last Linear (64 -> 3K+1 parameters of the transformed dim) is split by what the spline needs of it:
+//   * the 2K bin-size logits and the two boundary slope logits: ONE 32-row MFMA tile (kA3; half-wave 0's 16
+//     accumulator slots = K width logits, slot 14/15 = slope logits 0 / K; half-wave 1 the same with heights);
+//   * of the K+1 slope logits only the two of the bin that holds the sample are ever used: their columns
+//     are kept in accumulator order (kWS) and each lane gathers the pair of its bin after the bin search
+//     (2 x 32 v_fma + one half-wave add instead of a second 32-row MFMA tile: 2048 MFMA cycles -> 280).
+constexpr int kSlopeStride = 13;       // K + 1 <= 13 slope columns per hidden unit
 constexpr int kA2 = 0;                 // [32 kstep][64 lane][2 mtile]   W2 (scaled 2^64)
-constexpr int kA3 = 4096;              // [32 kstep'][64 lane][2 mtile'] last Linear, k in accumulator order
-constexpr int kW1B1 = 8192;            // [64 k][2]
+constexpr int kA3 = 4096;              // [8 kgroup][64 lane][4 kstep']  bin-size + boundary-slope rows, k in accumulator order
+constexpr int kWS = kA3 + 2048;        // [2 half][32 slot][kSlopeStride] slope columns, hidden units in accumulator order
+constexpr int kW1B1 = kWS + 2 * 32 * kSlopeStride;  // [64 k][2]
 constexpr int kB2 = kW1B1 + 128;       // [2 half][2 mtile][16 reg]
-constexpr int kB3 = kB2 + 64;          // [2 half][2 mtile'][16 reg']    bias of the parameters each half owns
-constexpr int kLayerFloats = kB3 + 64; // 8448 floats = 33,792 B
+constexpr int kB3 = kB2 + 64;          // [2 half][16 slot]               bias of the rows each half owns
+constexpr int kBS = kB3 + 32;          // [kSlopeStride] + pad            bias of the slope logits
+constexpr int kLayerFloats = kBS + 16; // 7216 floats = 28,864 B
+constexpr int kSlotSlopeFirst = 14, kSlotSlopeLast = 15;
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                 const float* b3, int cond_dim, int K, float* image);
 int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStream_t stream, int* out_grid);

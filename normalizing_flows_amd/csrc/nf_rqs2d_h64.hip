@@ -7,14 +7,19 @@
 // Same skeleton as nf_affine2d_h64.hip (first Linear generated in the MFMA B-operand
 // layout, 64x64 Linear on v_mfma_f32_32x32x2_f32, accumulator = next operand), plus:
 //   * the last Linear (64 -> 3K+1 parameters of the ONE transformed dim; the masked dim's
-//     37 are never read by MaskedCoupling and are not computed) is a second MFMA pass whose
-//     B operand is relu(accumulator) taken register by register, with the k order of the
-//     weight image permuted to the accumulator's order -- no lane movement, no LDS;
-//   * the rows of that last Linear are assigned so that half-wave 0 receives the K width
-//     logits + K+1 slope logits and half-wave 1 the K height logits + K+1 slope logits of
-//     its sample: each half builds its own knots, the half that owns the search axis finds
-//     the bin, and three v_permlane32_swap carry (bin index, knot pair) across;
-//   * a layer's weight image is 33,792 B, so layers are streamed through a double buffer in
+//     parameters are never read by MaskedCoupling and are not computed) is split by use:
+//     the 2K bin-size logits + the two boundary slope logits are ONE more 32-row MFMA tile whose
+//     B operand is relu(accumulator) taken register by register (weight image k-permuted to the
+//     accumulator's order -- no lane movement, no LDS); of the K+1 slope logits a sample only
+//     ever needs the two of its bin, so those two dot products are gathered after the bin search
+//     (per lane: 32 LDS reads of a column pair + 64 v_fma on its 32 hidden units, one
+//     v_permlane32_swap add).  The first build computed all 3K+1 (padded to 64 rows, K+1 slopes
+//     in both half-waves): 128 MFMAs per tile and layer, 20 % of them on zero rows; now 96.
+//   * half-wave 0 receives the K width logits of its sample, half-wave 1 the K height logits:
+//     each half builds its own knots (float64 normalisation, nf_rqs2d_common.h), the half that
+//     owns the search axis finds the bin, three v_permlane32_swap carry (bin index, knot pair)
+//     across, both halves finish with identical bits;
+//   * a layer's weight image is 28,864 B, so layers are streamed through a double buffer in
 //     LDS: the workgroup walks the chain layer by layer with one barrier per layer while the
 //     next layer's image is fetched (the flow state of every sample stays in registers).
 #include "nf_rqs2d_common.h"
@@ -29,6 +34,14 @@ namespace rqs2d {
 
 constexpr int kReluShift = 64;  // see nf_affine2d_h64.hip
 
+// row of the 32-row parameter tile that lands in half-wave `half`, accumulator slot q: the parameter it holds
+static inline int tile_param(int half, int q, int K) {
+  if (q < K) return half == 0 ? q : K + q;   // width / height logit q
+  if (q == kSlotSlopeFirst) return 2 * K;     // slope logit 0 (lower tail)
+  if (q == kSlotSlopeLast) return 3 * K;      // slope logit K (upper tail)
+  return -1;
+}
+
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                 const float* b3, int cond_dim, int K, float* img) {
   const int P = 3 * K + 1;
@@ -41,29 +54,39 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
         const int u = 32 * m + (lane & 31);
         img[kA2 + (s * 64 + lane) * 2 + m] = ldexpf(W2[k * 64 + u], kReluShift);
       }
-  // third pass: k-step s' = (m, r) of the accumulator, lane (u, hk): hidden unit j of that step
+  // second pass: k-step s = (m, r) of the accumulator, lane (u, hk): hidden unit j of that step; output row u
+  // of the tile lands in half hD, slot rr
   for (int m = 0; m < 2; ++m)
     for (int r = 0; r < 16; ++r)
       for (int lane = 0; lane < 64; ++lane) {
         const int hk = lane >> 5, u = lane & 31;
         const int j = 32 * m + 8 * (r >> 2) + 4 * hk + (r & 3);
         const int hD = (u >> 2) & 1, rr = (u & 3) + 4 * (u >> 3);
-        for (int mo = 0; mo < 2; ++mo) {
-          const int p = param_of_slot(hD, 16 * mo + rr, K);
-          img[kA3 + ((m * 16 + r) * 64 + lane) * 2 + mo] = p >= 0 ? W3[(size_t)j * (2 * P) + dT * P + p] : 0.f;
-        }
+        const int prm = tile_param(hD, rr, K);
+        const int s = m * 16 + r;
+        img[kA3 + ((s >> 2) * 64 + lane) * 4 + (s & 3)] = prm >= 0 ? W3[(size_t)j * (2 * P) + dT * P + prm] : 0.f;
       }
+  // slope columns, hidden units in the order a lane of half h holds them (slot = m*16 + r)
+  for (int h = 0; h < 2; ++h)
+    for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * m + 8 * (r >> 2) + 4 * h + (r & 3);
+        for (int c = 0; c <= K; ++c)
+          img[kWS + (h * 32 + m * 16 + r) * kSlopeStride + c] = W3[(size_t)j * (2 * P) + dT * P + 2 * K + c];
+      }
+  for (int c = 0; c <= K; ++c) img[kBS + c] = b3[dT * P + 2 * K + c];
   for (int k = 0; k < 64; ++k) {
     img[kW1B1 + 2 * k + 0] = ldexpf(W1[cond_dim * 64 + k], -kReluShift);
     img[kW1B1 + 2 * k + 1] = ldexpf(b1[k], -kReluShift);
   }
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h) {
     for (int m = 0; m < 2; ++m)
-      for (int r = 0; r < 16; ++r) {
-        img[kB2 + (h * 2 + m) * 16 + r] = b2[32 * m + 8 * (r >> 2) + 4 * h + (r & 3)];
-        const int p = param_of_slot(h, 16 * m + r, K);
-        img[kB3 + (h * 2 + m) * 16 + r] = p >= 0 ? b3[dT * P + p] : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) img[kB2 + (h * 2 + m) * 16 + r] = b2[32 * m + 8 * (r >> 2) + 4 * h + (r & 3)];
+    for (int q = 0; q < 16; ++q) {
+      const int prm = tile_param(h, q, K);
+      img[kB3 + h * 16 + q] = prm >= 0 ? b3[dT * P + prm] : 0.f;
+    }
+  }
 }
 
 template <int T, int WAVES, int INV, int K>
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
       if (live) {
       const float* L = lds + (step & 1) * kLayerFloats;
       const float2* a2 = reinterpret_cast<const float2*>(L + kA2) + lane;
-      const float2* a3 = reinterpret_cast<const float2*>(L + kA3) + lane;
+      const float4* a3 = reinterpret_cast<const float4*>(L + kA3) + lane;
       const float2* w1b1 = reinterpret_cast<const float2*>(L + kW1B1) + h;
 
       f32x16 acc[T][2];
@@ -169,41 +192,56 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
         }
       }
 
-      // last Linear: B operand = relu(accumulator register), k order = accumulator order
-      f32x16 out[T][2];
-      {
-        const f32x16 pb0 = lds_f32x16(L + kB3 + (h * 2 + 0) * 16);
-        const f32x16 pb1 = lds_f32x16(L + kB3 + (h * 2 + 1) * 16);
+      // second hidden activation, in place: the B operand of the next pass and the input of the slope gather
+#pragma unroll
+      for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float2 a = a3[(m * 16 + r) * 64];
+          for (int r = 0; r < 16; ++r) acc[t][m][r] = fmaxf(acc[t][m][r], 0.f);
+
+      // bin-size logits + boundary slope logits: one 32-row tile, k order = accumulator order
+      f32x16 out[T];
+      {
+        const f32x16 pb = lds_f32x16(L + kB3 + h * 16);
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-              const float b = fmaxf(acc[t][m][r], 0.f);
-              if (m == 0 && r == 0) {
-                out[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, pb0, 0, 0, 0);
-                out[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, pb1, 0, 0, 0);
-              } else {
-                out[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, out[t][0], 0, 0, 0);
-                out[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, out[t][1], 0, 0, 0);
-              }
-            }
+        for (int g = 0; g < 8; ++g) {
+          const float4 a = a3[g * 64];
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const int m = g >> 2, r = (g & 3) * 4;
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[t][m][r + 0], g == 0 ? pb : out[t], 0, 0, 0);
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[t][m][r + 1], out[t], 0, 0, 0);
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc[t][m][r + 2], out[t], 0, 0, 0);
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc[t][m][r + 3], out[t], 0, 0, 0);
           }
+        }
       }
 
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        float slot[32], lg[K], sg[K + 1];
+        float lg[K], knot[K + 1];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { slot[q] = out[t][0][q]; slot[16 + q] = out[t][1][q]; }
+        for (int k = 0; k < K; ++k) lg[k] = out[t][k];
+        knots_f64<K, NF_RQS_XEXP>(lg, p, knot);
+        float xl, xr, yl, yr;
+        const int kb = spline_bin<K, INV>(knot, xt[t], h, &xl, &xr, &yl, &yr);
+        // slope logits kb and kb + 1: this lane's 32 hidden units against the two columns, then the other half's
+        const float* ws = L + kWS + h * (32 * kSlopeStride) + kb;
+        float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) lg[k] = slot[k];
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int k = 0; k <= K; ++k) sg[k] = slot[K + k];
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][m][r];
+            d0 = fmaf(v, ws[(m * 16 + r) * kSlopeStride], d0);
+            d1 = fmaf(v, ws[(m * 16 + r) * kSlopeStride + 1], d1);
+          }
+        const float raw_l = add_halves(d0) + L[kBS + kb];
+        const float raw_r = add_halves(d1) + L[kBS + kb + 1];
         float nt, l;
-        spline<K, INV>(lg, sg, xt[t], h, p, &nt, &l);
+        spline_map<INV>(xl, xr, yl, yr, raw_l, raw_r, out[t][kSlotSlopeFirst], out[t][kSlotSlopeLast], xt[t], p,
+                        &nt, &l);
         ld[t] += l;
         xt[t] = xc[t];
         xc[t] = nt;

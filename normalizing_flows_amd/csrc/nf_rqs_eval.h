@@ -4,90 +4,48 @@
 #pragma once
 
 #include "nf_internal.h"
+#include "nf_rqs_math.h"
 
 namespace nf {
 namespace generic {
 
 typedef float f32x16_rqs __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
-__device__ __forceinline__ float softplus_fast(float v) {
-  return fmaxf(v, 0.f) + flog(1.f + fexp2(-fabsf(v) * 1.44269504f));
-}
-
+// One (row, transformed dim) with the 3K+1 raw parameters at p [widths K | heights K | slopes K+1]: the search
+// axis first (its knots, the bin), then the other axis' knots of that bin -- one axis' float64 bin weights live
+// at a time.  Arithmetic: nf_rqs_math.h.
 template <int K, int INV>
 __device__ __forceinline__ void rqs_eval_reg(const float* __restrict__ p, const RqsConst& c, float v, float* out,
                                              float* logdet) {
-  constexpr float kL2E = 1.44269504f;
-  const float total = c.range_max - c.range_min;
-  float lw[K], lh[K];
-  float mw = -INFINITY, mh = -INFINITY;
+  float lg[K], knot[K + 1];
+  // search axis: x (widths) going forward, y (heights) inversely
 #pragma unroll
-  for (int k = 0; k < K; ++k) { lw[k] = p[k]; lh[k] = p[K + k]; mw = fmaxf(mw, lw[k]); mh = fmaxf(mh, lh[k]); }
-  float sw = 0.f, sh = 0.f;
-  const float mwl = -mw * kL2E, mhl = -mh * kL2E;
+  for (int k = 0; k < K; ++k) lg[k] = p[(INV ? K : 0) + k];
+  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot);
+  int kb = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    lw[k] = fexp2(fmaf(lw[k], kL2E, mwl)); sw += lw[k];
-    lh[k] = fexp2(fmaf(lh[k], kL2E, mhl)); sh += lh[k];
-  }
-  const float scw = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sw);
-  const float sch = (total - (float)K * c.min_bin) * __builtin_amdgcn_rcpf(sh);
-  // walk the knots, keep the bin that contains v on the search axis
-  float xl = c.range_min, yl = c.range_min;
-  float bxl = xl, byl = yl, bxr = 0.f, byr = 0.f, rsl = p[2 * K], rsr = p[2 * K + 1];
+  for (int k = 1; k < K; ++k) kb += (v >= knot[k]) ? 1 : 0;
+  float slo = knot[0], shi = knot[1], raw_l = p[2 * K], raw_r = p[2 * K + 1];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float xr = k == K - 1 ? c.range_max : xl + fmaf(lw[k], scw, c.min_bin);
-    const float yr = k == K - 1 ? c.range_max : yl + fmaf(lh[k], sch, c.min_bin);
-    if (k == 0) { bxr = xr; byr = yr; }
-    else {
-      const bool hit = v >= (INV ? yl : xl);   // the last bin whose left knot is <= v
-      bxl = hit ? xl : bxl; bxr = hit ? xr : bxr;
-      byl = hit ? yl : byl; byr = hit ? yr : byr;
-      rsl = hit ? p[2 * K + k] : rsl;
-      rsr = hit ? p[2 * K + k + 1] : rsr;
-    }
-    xl = xr; yl = yr;
+  for (int k = 1; k < K; ++k) {
+    const bool hit = kb >= k;
+    slo = hit ? knot[k] : slo;
+    shi = hit ? knot[k + 1] : shi;
+    raw_l = hit ? p[2 * K + k] : raw_l;
+    raw_r = hit ? p[2 * K + k + 1] : raw_r;
   }
-  const float sl = softplus_fast(rsl + c.slope_offset) + c.min_slope;
-  const float sr = softplus_fast(rsr + c.slope_offset) + c.min_slope;
-  const float bw = bxr - bxl, bh = byr - byl;
-  const float rbw = __builtin_amdgcn_rcpf(bw);
-  const float delta = bh * rbw;
-  const float st = sr + sl - 2.f * delta;
-  float res, ldv;
-  if (!INV) {
-    float z = (v - bxl) * rbw;
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
-    res = fmaf(bh * (delta * zz + sl * z1mz), rden, byl);
-    ldv = flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
-  } else {
-    float u = (v - byl) * __builtin_amdgcn_rcpf(bh);
-    u = fminf(fmaxf(u, 0.f), 1.f);
-    const float qc = -delta * u, qb = sl - st * u, qa = delta - qb;
-    float z = -2.f * qc * __builtin_amdgcn_rcpf(qb + __builtin_amdgcn_sqrtf(qb * qb - 4.f * qa * qc));
-    z = fminf(fmaxf(z, 0.f), 1.f);
-    res = fmaf(bw, z, bxl);
-    const float zz = z * z, z1mz = z - zz, omz = 1.f - z;
-    const float rden = __builtin_amdgcn_rcpf(delta + st * z1mz);
-    ldv = -flog(delta * delta * (sr * zz + 2.f * delta * z1mz + sl * omz * omz) * rden * rden);
+#pragma unroll
+  for (int k = 0; k < K; ++k) lg[k] = p[(INV ? 0 : K) + k];
+  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot);
+  float olo = knot[0], ohi = knot[1];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const bool hit = kb >= k;
+    olo = hit ? knot[k] : olo;
+    ohi = hit ? knot[k + 1] : ohi;
   }
-  if (v <= c.range_min || v >= c.range_max) {  // linear tails
-    const bool below = v <= c.range_min;
-    const float edge = below ? c.range_min : c.range_max;
-    const float s = softplus_fast(p[below ? 2 * K : 3 * K] + c.slope_offset) + c.min_slope;
-    res = INV ? (v - edge) * __builtin_amdgcn_rcpf(s) + edge : (v - edge) * s + edge;
-    ldv = INV ? -flog(s) : flog(s);
-  }
-  // jnp.clip keeps NaN, fmaxf / fminf above do not: a NaN coordinate stays NaN (integer test: the
-  // kernels are built with -fno-honor-nans)
-  const bool v_nan = (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u;
-  *out = v_nan ? v : res;
-  *logdet = v_nan ? v : ldv;
+  const float xl = INV ? olo : slo, xr = INV ? ohi : shi, yl = INV ? slo : olo, yr = INV ? shi : ohi;
+  rqsmath::rqs_map<INV, false>(xl, xr, yl, yr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
 }
 
 constexpr int kCtStride = 129;  // floats per row of the staged result tile (odd: conflict-free column reads)

@@ -334,3 +334,9 @@ class CouplingFlow:
     def attach_comm(self, comm) -> None:
         check(self._lib.nf_flow_attach_comm(self._h, comm._h if comm is not None else None))
         self._comm = comm
+
+    def collective_count(self) -> int:
+        """Collectives this handle has issued (nf_flow_collective_count): must agree across ranks."""
+        n = C.c_uint64(0)
+        check(self._lib.nf_flow_collective_count(self._h, C.byref(n)))
+        return int(n.value)

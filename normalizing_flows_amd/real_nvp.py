@@ -7,6 +7,8 @@ evaluation lowered to the fused split-coupling kernel of libnf_hip
 """
 from __future__ import annotations
 
+import hashlib
+from collections import OrderedDict
 from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
@@ -46,12 +48,31 @@ def shift_and_log_scale_fn(net_params: NetParams, x) -> Tuple[np.ndarray, np.nda
     return y[:, 1:2], ld[:, None]
 
 
-# handles are cached per parameter identity: the scripts call these functions in a loop
-_CACHE = {}
+# Handles are cached by parameter CONTENT (shapes + a digest of the bytes; the reference's conditioner is 18
+# floats per layer, so hashing costs less than the ctypes call).  JAX arrays are immutable and a reference
+# script can only ever pass new arrays; NumPy callers can also update in place (`W -= lr * g`), which an
+# identity key would miss -- the digest sees it and the flow is rebuilt with the new weights.
+_CACHE: "OrderedDict[tuple, CouplingFlow]" = OrderedDict()
+_CACHE_MAX = 16
 
 
 def _signature(params: Sequence[NetParams]):
-    return tuple(id(a) for net in params for lin in net for a in lin)
+    h = hashlib.blake2b(digest_size=16)
+    shapes = []
+    for net in params:
+        for lin in net:
+            for a in lin:
+                a = np.ascontiguousarray(a, np.float32)
+                shapes.append(a.shape)
+                h.update(a.tobytes())
+    return (tuple(shapes), h.digest())
+
+
+def _cache_put(key, flow: CouplingFlow) -> None:
+    _CACHE[key] = flow
+    _CACHE.move_to_end(key)
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
 
 
 def _chain_for(params: Sequence[NetParams], flips: Sequence[bool]) -> CouplingFlow:
@@ -62,7 +83,8 @@ def _chain_for(params: Sequence[NetParams], flips: Sequence[bool]) -> CouplingFl
     key = (_signature(params), tuple(flips))
     hit = _CACHE.get(key)
     if hit is not None:
-        return hit[0]
+        _CACHE.move_to_end(key)
+        return hit
     first = params[0]
     d_in = np.asarray(first[0][0]).shape[0]
     d_out = np.asarray(first[-1][0]).shape[1]
@@ -72,9 +94,7 @@ def _chain_for(params: Sequence[NetParams], flips: Sequence[bool]) -> CouplingFl
                      hidden=tuple(np.asarray(W).shape[1] for W, _ in first[:-1]),
                      activation=_lib.ACT_LEAKY_RELU, first_mask_parity=int(flips[0]))
     flow = CouplingFlow(cfg, [[(np.asarray(W), np.asarray(b)) for W, b in net] for net in params])
-    if len(_CACHE) > 64:
-        _CACHE.clear()
-    _CACHE[key] = (flow, [a for net in params for lin in net for a in lin])  # keep ids alive
+    _cache_put(key, flow)
     return flow
 
 
@@ -178,9 +198,12 @@ def sgd_update(params, fns_config, batch, learning_rate: float = 1e-2):
     for fn, _ in fns_config:
         _require_fn(fn)
     flips = [flip for _, flip in fns_config]
+    old_key = (_signature(params), tuple(bool(f) for f in flips))
     flow = _chain_for(params, flips)
     nll = flow.train_step(np.ascontiguousarray(batch, np.float32), training.sgd(learning_rate))
     new_params = [[[W, b] for W, b in layer] for layer in flow.get_weights()]
-    # the handle now holds the new weights: keep it for the next call on these arrays
-    _CACHE[(_signature(new_params), tuple(bool(f) for f in flips))] = (flow, [a for net in new_params for lin in net for a in lin])
+    # the handle now holds the NEW weights: move it to their key, so that the old params no longer reach it
+    # (a later loss(old_params, ...) builds a flow of its own) and the 50,001-step loop keeps one entry
+    _CACHE.pop(old_key, None)
+    _cache_put((_signature(new_params), tuple(bool(f) for f in flips)), flow)
     return nll, new_params

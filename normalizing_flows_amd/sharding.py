@@ -37,6 +37,30 @@ def shard_rows(rows_global: int, world: int, rank: int, align: int = 2) -> Tuple
     return begin, end
 
 
+class RanksDisagree(RuntimeError):
+    """Raised on EVERY rank when at least one rank reported a failure (or a different value)."""
+
+
+def agree_all(dist, ok: bool, what: str, detail: str = "") -> None:
+    """All ranks call this at the same point with their own verdict; if any rank says `ok=False` every rank
+    raises RanksDisagree (naming the failing ranks and their messages) -- nobody walks on into a collective
+    the failed rank will never join.  `dist` is a torch.distributed-like module on a CPU (gloo) group."""
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, (bool(ok), str(detail)))
+    bad = [(r, msg) for r, (good, msg) in enumerate(box) if not good]
+    if bad:
+        raise RanksDisagree(f"{what}: failed on rank(s) " + "; ".join(f"{r} ({msg or 'no detail'})" for r, msg in bad))
+
+
+def agree_equal(dist, value, what: str) -> None:
+    """All ranks call this with a value that must be the same everywhere (e.g. CouplingFlow.collective_count());
+    every rank raises RanksDisagree when it is not."""
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, value)
+    if any(v != box[0] for v in box):
+        raise RanksDisagree(f"{what}: ranks disagree: " + ", ".join(f"rank {r}: {v}" for r, v in enumerate(box)))
+
+
 class RcclComm:
     """One RCCL communicator (one rank per GPU)."""
 
@@ -54,13 +78,49 @@ class RcclComm:
         check(_lib.load().nf_comm_unique_id(buf))
         return buf.raw
 
+    @staticmethod
+    def preflight() -> None:
+        """nf_comm_preflight: a usable device is current and librccl loads.  Raises NFError otherwise."""
+        check(_lib.load().nf_comm_preflight())
+
     @classmethod
     def from_torch_distributed(cls, dist) -> "RcclComm":
-        """Rank 0 makes the id; the (CPU) process group carries it to the others."""
+        """Rank 0 makes the id; the (CPU) process group carries it to the others.
+
+        ncclCommInitRank blocks until every rank has entered it, so everything that can fail on ONE rank is
+        done and agreed on (over the CPU group) BEFORE any rank enters it: the preflight (device + librccl)
+        and the making of the id.  After the init the outcome is agreed on again, so that a rank whose init
+        returned an error does not leave the others to find out at their first all-reduce.  On any failure
+        every rank raises RanksDisagree."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.new_unique_id() if rank == 0 else None]
+        try:
+            cls.preflight()
+            ok, detail = True, ""
+        except Exception as exc:  # reported to every rank below
+            ok, detail = False, f"{type(exc).__name__}: {exc}"
+        agree_all(dist, ok, "RCCL preflight (device + librccl)", detail)
+        uid, ok, detail = None, True, ""
+        if rank == 0:
+            try:
+                uid = cls.new_unique_id()
+            except Exception as exc:
+                ok, detail = False, f"{type(exc).__name__}: {exc}"
+        agree_all(dist, ok, "ncclGetUniqueId", detail)
+        box = [uid]
         dist.broadcast_object_list(box, src=0)
-        return cls(world, rank, box[0])
+        comm = None
+        try:
+            comm = cls(world, rank, box[0])
+            ok, detail = True, ""
+        except Exception as exc:
+            ok, detail = False, f"{type(exc).__name__}: {exc}"
+        try:
+            agree_all(dist, ok, "ncclCommInitRank", detail)
+        except RanksDisagree:
+            if comm is not None:
+                comm.close()
+            raise
+        return comm
 
     def close(self) -> None:
         if self._h is not None and self._h.value:

@@ -1,4 +1,5 @@
-"""One rank of tests/test_abi_and_host.py::test_sharded_nll_gloo_world2."""
+"""One rank of the world-size-2 gloo tests in tests/test_abi_and_host.py.
+    _gloo_worker.py RANK WORLD [nll | onesided | counts | preflight]"""
 import sys
 
 import numpy as np
@@ -9,9 +10,33 @@ from normalizing_flows_amd.sharding import ShardedNLL
 from oracle import flows_np as O
 
 
+def handshake(mode, rank, world):
+    """The failure paths bench.py relies on to exit instead of hanging inside RCCL (sharding.agree_all /
+    agree_equal / RcclComm.from_torch_distributed).  Prints one line and exits 0 when the expected error came."""
+    from normalizing_flows_amd import sharding
+    try:
+        if mode == "onesided":      # rank 1 alone reports a failure: BOTH ranks must raise, naming rank 1
+            sharding.agree_all(dist, rank != 1, "set-up step", "" if rank != 1 else "librccl missing (simulated)")
+        elif mode == "counts":      # the collective counts differ: both ranks must raise
+            sharding.agree_equal(dist, 7 + rank, "collectives issued")
+        elif mode == "preflight":   # no GPU here: the preflight fails on every rank before any ncclCommInitRank
+            sharding.RcclComm.from_torch_distributed(dist)
+        print(f"rank {rank} NO ERROR")
+        code = 1
+    except sharding.RanksDisagree as exc:
+        print(f"rank {rank} RanksDisagree: {exc}")
+        code = 0
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(code)
+
+
 def main():
     rank, world = int(sys.argv[1]), int(sys.argv[2])
+    mode = sys.argv[3] if len(sys.argv) > 3 else "nll"
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode != "nll":
+        handshake(mode, rank, world)
     spec = O.make_affine_spec(4, final_std=0.02)
     x = O.make_inputs("banana", 4097)
 

@@ -243,6 +243,30 @@ def test_sharded_nll_gloo_world2():
     assert abs(vals[0] - O.nll(spec, x)) < 1e-12
 
 
+@pytest.mark.parametrize("mode,port", [("onesided", "29641"), ("counts", "29642"), ("preflight", "29643")])
+def test_multirank_failures_raise_on_every_rank(mode, port):
+    """What keeps a one-sided failure from hanging the peers inside ncclCommInitRank / the next all-reduce
+    (the mean the collective implements: /root/reference src/real_nvp_toy_densities.py:143,150):
+    every step that can fail on one rank is agreed on over the CPU group first, so ALL ranks raise.
+    `preflight`: no GPU in this container, so nf_comm_preflight fails on both ranks and
+    RcclComm.from_torch_distributed must stop before any rank calls ncclCommInitRank (skipped on a GPU box)."""
+    from normalizing_flows_amd import _lib
+    if mode == "preflight" and _lib.device_count() > 0:
+        pytest.skip("a GPU is visible: the preflight succeeds here")
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", mode], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for r, o in enumerate(outs):
+        assert f"rank {r} RanksDisagree" in o, o
+    if mode == "onesided":
+        assert all("rank(s) 1 (librccl missing (simulated))" in o for o in outs), outs
+    if mode == "counts":
+        assert all("rank 0: 7, rank 1: 8" in o for o in outs), outs
+
+
 def test_prepare_data_matches_the_reference_arithmetic():
     """src/maf_mnist.py:101-106: float32(image) / 256, noise in [0, 1) only with a key."""
     from normalizing_flows_amd import prepare_data

@@ -107,6 +107,34 @@ def test_hand_computed_case():
     assert np.allclose(xb, g["x"], atol=1e-12) and np.allclose(ldb, [-0.5], atol=1e-12)
 
 
+def test_hand_computed_rqs_case():
+    """A spline layer worked by hand (tests/golden/make_golden.py:hand_case_rqs -- rational arithmetic + math.log,
+    no oracle call): both bins, the inner knot itself, both linear tails.  Pins the oracle's reading of
+    distrax.RationalQuadraticSpline by an independent derivation.  The float32 rounding of
+    the weights (r_k / 4, r_k / 7) moves the results by ~1e-7."""
+    g = np.load(os.path.join(GOLD, "rqs_hand_case.npz"))
+    spec = O.FlowSpec("rqs", 2, [[(g["W1"], g["b1"]), (g["W2"], g["b2"]), (g["W3"], g["b3"])]],
+                      [np.array([False, True])], num_bins=int(g["num_bins"]), range_min=float(g["range_min"]),
+                      range_max=float(g["range_max"]), min_bin_size=float(g["min_bin_size"]),
+                      min_knot_slope=float(g["min_knot_slope"]))
+    raw = O.conditioner_apply(spec.layers[0], np.array([[0.0, 2.0]]))[0, :7]
+    xp, yp, sl = O.rqs_knots(raw[None], -2.0, 2.0, 0.5, 0.5)
+    assert np.allclose(xp, [[-2, -0.75, 2]], atol=1e-6) and np.allclose(yp, [[-2, 0.75, 2]], atol=1e-6)
+    assert np.allclose(sl, [[1.0, 2.0, 1.5]], atol=1e-6)
+    y, ld = O.coupling_layer(spec, 0, g["x"], False)
+    assert np.allclose(y, g["y"], atol=2e-6) and np.allclose(ld, g["logdet"], atol=2e-6)
+    assert np.allclose(O.log_prob(spec, g["x"]), g["log_prob"], atol=4e-6)
+    xb, ldb = O.coupling_layer(spec, 0, y, True)
+    assert np.allclose(xb, g["x"], atol=1e-9) and np.allclose(ldb, -ld, atol=1e-9)
+    # the 4-bin case of the same generator (a bin count the fused kernel takes)
+    spec = O.FlowSpec("rqs", 2, [[(g["W1_k4"], g["b1_k4"]), (g["W2_k4"], g["b2_k4"]), (g["W3_k4"], g["b3_k4"])]],
+                      [np.array([False, True])], num_bins=4, range_min=-2.0, range_max=2.0,
+                      min_bin_size=float(g["min_bin_size_k4"]), min_knot_slope=0.5)
+    y, ld = O.coupling_layer(spec, 0, g["x_k4"], False)
+    assert np.allclose(y, g["y_k4"], atol=2e-6) and np.allclose(ld, g["logdet_k4"], atol=2e-6)
+    assert np.allclose(O.log_prob(spec, g["x_k4"]), g["log_prob_k4"], atol=4e-6)
+
+
 def test_variant_a_hand_case():
     """src/real_nvp.py by hand: MLP 1->1->2 on y=(1,3), no flip.
     act = leaky(1*2-3) = leaky(-1) = -0.01; out = -0.01*(10, 20) + (0.3, 0.2) = (0.2, 0.0)

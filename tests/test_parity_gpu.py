@@ -20,10 +20,13 @@ pytestmark = pytest.mark.gpu
 DENSITIES = ["banana", "energy1", "energy2", "energy3", "energy4", "gaussian_blobs"]
 
 
-# Spline-path intermediates: how many times the NumPy float32 restatement's own worst error on
-# the same batch a float32 kernel may be away from float64 (see assert_close).  4 is calibrated on
-# the exact-float32 kernels; tests/test_bf16x3_gpu.py re-runs these tests with its own value.
-FLOOR = 4.0
+# Spline paths: a sample whose float64 value an all-float32 evaluation cannot reach either (a nearly flat or nearly
+# vertical piece of the spline: the NumPy float32 restatement itself is further than 1e-5 away there) is allowed
+# SPLINE_F32_FACTOR times the float32 restatement's own error ON THAT SAMPLE -- never a batch-wide floor.  Measured
+# (tests/tools/rqs_error_stats.py): the kernels carry the knots in float64 and sit 5-6x closer to
+# float64 than NumPy float32 does (log_prob worst 1.0e-6 ... 6.6e-6 scaled on configs[2]), so the escape only
+# matters for a handful of ill-conditioned samples per 16,384.
+SPLINE_F32_FACTOR = 2.0
 
 
 def tol(ref):
@@ -31,10 +34,7 @@ def tol(ref):
 
 
 def assert_close(got, ref, what, floor=0.0):
-    """`floor` (used only for the spline path's intermediate outputs) widens the tolerance to
-    four times the worst error the NumPy float32 restatement itself makes on the same batch
-    (the 8-layer spline chain amplifies float32 rounding; both float32 computations are noise
-    around the float64 value, so a factor between them is all that can be asserted)."""
+    """|got - ref| <= 1e-5 * max(1, |ref|) (+ an absolute `floor`, used only by a few single-layer checks)."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
@@ -42,6 +42,56 @@ def assert_close(got, ref, what, floor=0.0):
     bad &= ~((got == ref))  # equal infinities
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.size} outside tolerance, worst abs "
                            f"{np.nanmax(np.abs(got - ref))} at ref {ref.ravel()[np.nanargmax(np.abs(got - ref))]}")
+
+
+def spline_ok(got, ref, ref32):
+    """Per element: within 1e-5 * max(1, |ref|), or within SPLINE_F32_FACTOR x the float32 restatement's own
+    error on the same element."""
+    got, ref, ref32 = (np.asarray(a, np.float64) for a in (got, ref, ref32))
+    assert got.shape == ref.shape == ref32.shape, (got.shape, ref.shape, ref32.shape)
+    err = np.abs(got - ref)
+    return (err <= np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(ref32 - ref))) | (got == ref)
+
+
+def assert_spline_close(got, ref, ref32, what):
+    ok = spline_ok(got, ref, ref32)
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert ok.all(), (f"{what}: {int((~ok).sum())}/{ok.size} outside max(1e-5 scaled, {SPLINE_F32_FACTOR} x float32's own "
+                      f"error), worst scaled {np.nanmax(np.where(ok, 0, err)):.3e} at ref "
+                      f"{ref.ravel()[np.nanargmax(np.where(ok, 0, err))]}")
+
+
+def assert_spline_forward(f, spec, x, what):
+    """log_prob, z and logdet of the density-evaluation walk against float64, per-sample bound."""
+    from normalizing_flows_amd import _lib
+    ref = O.log_prob(spec, x)
+    assert_spline_close(f.log_prob(x), ref, O.log_prob(spec, x, np.float32), f"{what} log_prob")
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    zr, ldr = O.chain_forward(spec, x)
+    z32, ld32 = O.chain_forward(spec, x, np.float32)
+    assert_spline_close(z, zr, z32, f"{what} z")
+    assert_spline_close(ld, ldr, ld32, f"{what} logdet")
+    return ref, z
+
+
+def assert_spline_inverse(f, spec, z, what):
+    """The generative walk x = chain^-1(z) and its logdet.  Where dx/dz is large the inverse is ill-conditioned
+    (NumPy float32 itself misses float64 by up to 1e-1 on single samples of an 11-layer chain), so a row passes
+    either by its forward error (per-sample bound, as everywhere) or by its BACKWARD error: the float64 forward walk
+    of the x the kernel returned lands on z within 1e-5 scaled, and -logdet_forward(x) is the logdet it returned."""
+    from normalizing_flows_amd import _lib
+    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xr, ldr = O.chain_inverse(spec, z)
+    x32, ld32 = O.chain_inverse(spec, z, np.float32)
+    fwd_ok = spline_ok(xb, xr, x32).all(axis=-1) & spline_ok(ldb, ldr, ld32)
+    zb, ldf = O.chain_forward(spec, xb)
+    zz = np.asarray(z, np.float64)
+    bwd_ok = (np.abs(zb - zz) <= tol(zz)).all(axis=-1) & (np.abs(np.asarray(ldb, np.float64) + ldf) <= tol(ldf))
+    ok = fwd_ok | bwd_ok | ~np.isfinite(xr).all(axis=-1)
+    assert ok.all(), (f"{what}: {int((~ok).sum())}/{ok.size} rows fail both the forward and the backward error bound; "
+                      f"worst |x - x64| {np.abs(xb - xr)[~ok].max():.3e}, |forward64(x) - z| {np.abs(zb - zz)[~ok].max():.3e}")
+    return xb
 
 
 @pytest.fixture(scope="module")
@@ -414,19 +464,8 @@ def test_rqs_toy_config3(nfa, density):
     spec = O.make_rqs_spec(8, final_std=0.05)
     f = rqs_flow(nfa, spec)
     x = O.make_inputs(density, 4096)
-    ref = O.log_prob(spec, x)
-    lp32 = O.log_prob(spec, x, np.float32)
-    assert_close(f.log_prob(x), ref, f"rqs log_prob {density}", FLOOR * np.abs(lp32 - ref).max())
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    zr, ldr = O.chain_forward(spec, x)
-    z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "rqs z", FLOOR * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, "rqs logdet", FLOOR * np.abs(ld32 - ldr).max())
-    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
-    xr, ldr2 = O.chain_inverse(spec, z)
-    x32, ldi32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "rqs inverse", FLOOR * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr2, "rqs inverse logdet", FLOOR * np.abs(ldi32 - ldr2).max())
+    ref, z = assert_spline_forward(f, spec, x, f"rqs {density}")
+    assert_spline_inverse(f, spec, z, f"rqs {density} inverse")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
 
 
@@ -527,7 +566,26 @@ def test_golden_vectors(nfa):
     cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), rqs_bins=12,
                          rqs_range_min=-8.0, rqs_range_max=8.0)
     f = nfa.CouplingFlow(cfg, unflat_affine(g["weights"], 8, out=74))
-    assert_close(f.log_prob(g["x"]), g["log_prob"], "golden rqs", 3e-5)
+    assert_close(f.log_prob(g["x"]), g["log_prob"], "golden rqs")
+    # the spline layer worked by hand (not an oracle product): both bins, the inner knot, both tails -- on the
+    # general path (hidden (2, 2)) and, zero-padded to 64/64 by nf_flow_create, on the fused kernel
+    g = np.load(os.path.join(GOLD, "rqs_hand_case.npz"))
+    for sfx, pad, kernel in (("", False, "generic_gemm"), ("_k4", False, "generic_gemm"), ("_k4", True, "rqs2d_h64_mfma")):
+        cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=1, hidden=(2, 2),
+                             rqs_bins=int(g["num_bins" + sfx]), rqs_range_min=-2.0, rqs_range_max=2.0,
+                             rqs_min_bin_size=float(g["min_bin_size" + sfx]), rqs_min_knot_slope=0.5)
+        with _no_pad(pad):
+            f = nfa.CouplingFlow(cfg, [[(g["W1" + sfx], g["b1" + sfx]), (g["W2" + sfx], g["b2" + sfx]),
+                                        (g["W3" + sfx], g["b3" + sfx])]])
+        assert f.kernel_name == kernel
+        x, yref, ldref = g["x" + sfx], g["y" + sfx], g["logdet" + sfx]
+        y, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+        assert_close(y, yref, f"rqs hand case y ({kernel}{sfx})")
+        assert_close(ld, ldref, f"rqs hand case logdet ({kernel}{sfx})")
+        assert_close(f.log_prob(x), g["log_prob" + sfx], f"rqs hand case log_prob ({kernel}{sfx})")
+        xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, yref.astype(np.float32))
+        assert_close(xb, x, f"rqs hand case inverse ({kernel}{sfx})")
+        assert_close(ldb, -ldref, f"rqs hand case inverse logdet ({kernel}{sfx})")
     g = np.load(os.path.join(GOLD, "affine_hand_case.npz"))
     cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=1, hidden=(2, 2))
     f = nfa.CouplingFlow(cfg, [[(g["W1"], g["b1"]), (g["W2"], g["b2"]), (g["W3"], g["b3"])]])
@@ -548,25 +606,15 @@ def test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi):
     f = rqs_flow(nfa, spec, parity)
     assert f.kernel_name == "rqs2d_h64_mfma"
     x = O.make_inputs("banana", rows, seed=K * 100 + L)   # banana leaves [-8, 8]: tails are exercised
-    ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, "fused rqs log_prob", FLOOR * e32)
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    zr, ldr = O.chain_forward(spec, x)
-    z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "fused rqs z", FLOOR * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, "fused rqs logdet", FLOOR * np.abs(ld32 - ldr).max())
-    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
-    xr, ldr2 = O.chain_inverse(spec, z)
-    x32, l32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "fused rqs inverse", FLOOR * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr2, "fused rqs inverse logdet", FLOOR * np.abs(l32 - ldr2).max())
+    ref, z = assert_spline_forward(f, spec, x, "fused rqs")
+    assert_spline_inverse(f, spec, z, "fused rqs inverse")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
     for l in range(min(L, 3)):
         y, d = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, l, l + 1)
         yr, dr = O.coupling_layer(spec, l, x, False)
-        assert_close(y, yr, f"fused rqs layer {l}", 1e-5)
-        assert_close(d, dr, f"fused rqs layer {l} logdet", 2e-5)
+        y32, d32 = O.coupling_layer(spec, l, x, False, np.float32)
+        assert_spline_close(y, yr, y32, f"fused rqs layer {l}")
+        assert_spline_close(d, dr, d32, f"fused rqs layer {l} logdet")
 
 
 def test_rqs_fused_identity_and_edges(nfa):
@@ -579,7 +627,7 @@ def test_rqs_fused_identity_and_edges(nfa):
     assert np.abs(y - x).max() <= 1e-5 and np.abs(ld).max() <= 1e-5
     spec2 = O.make_rqs_spec(3, final_std=0.5, num_bins=8, range_min=-2.0, range_max=2.0, first_parity=0)
     f2 = rqs_flow(nfa, spec2, 0)
-    assert_close(f2.log_prob(x), O.log_prob(spec2, x), "fused rqs edge inputs", 2e-5)
+    assert_spline_close(f2.log_prob(x), O.log_prob(spec2, x), O.log_prob(spec2, x, np.float32), "fused rqs edge inputs")
 
 
 @pytest.mark.parametrize("K,D,hidden,L,rows", [(12, 2, (64, 64), 8, 4096), (8, 2, (64, 64), 3, 1000),
@@ -594,15 +642,8 @@ def test_rqs_general_path_register_kernel(nfa, monkeypatch, K, D, hidden, L, row
     f = rqs_flow(nfa, spec)
     assert f.kernel_name == "generic_gemm"
     x = (np.random.default_rng(K + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
-    ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, "general rqs log_prob", FLOOR * e32)
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
-    xr, ldr = O.chain_inverse(spec, z)
-    x32, l32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "general rqs inverse", FLOOR * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr, "general rqs inverse logdet", FLOOR * np.abs(l32 - ldr).max())
+    ref, z = assert_spline_forward(f, spec, x, "general rqs")
+    assert_spline_inverse(f, spec, z, "general rqs inverse")
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
@@ -624,28 +665,20 @@ def test_rqs_spline_in_gemm_epilogue(nfa, monkeypatch, mode, K, D, hidden, L, ro
     x = (np.random.default_rng(K * 100 + D).standard_normal((rows, D)) * 2.5).astype(np.float32)
     x[0, 0] = 7.5       # linear tail
     x[-1, D - 1] = -5.0  # range edge
-    ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
     f = rqs_flow(nfa, spec, parity)
     f.set_option("hidden_matmul", mode)
     assert f.kernel_name == "generic_gemm"
+    ref, z = assert_spline_forward(f, spec, x, "K5")
+    assert_spline_inverse(f, spec, z, "K5 inverse")
     got = f.log_prob(x)
-    assert_close(got, ref, "K5 log_prob", FLOOR * e32)
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    zr, ldr = O.chain_forward(spec, x)
-    z32, l32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "K5 forward", FLOOR * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, "K5 forward logdet", FLOOR * np.abs(l32 - ldr).max())
-    xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
-    xr, ldr = O.chain_inverse(spec, z)
-    x32, l32 = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, "K5 inverse", FLOOR * np.abs(x32 - xr).max())
-    assert_close(ldb, ldr, "K5 inverse logdet", FLOOR * np.abs(l32 - ldr).max())
     monkeypatch.setenv("NF_NO_K5", "1")
     g = rqs_flow(nfa, spec, parity)
     g.set_option("hidden_matmul", mode)
     plain = g.log_prob(x)
-    assert np.abs(plain.astype(np.float64) - got).max() <= 2 * max(FLOOR * e32, float(tol(ref).max()))
+    # the unfused form of the same arithmetic: both within the bound of float64, hence within twice it of each other
+    lp32 = O.log_prob(spec, x, np.float32)
+    assert_spline_close(plain, ref, lp32, "unfused log_prob")
+    assert (np.abs(plain.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(lp32 - ref))).all()
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
@@ -666,15 +699,15 @@ def test_narrow_2d_flows_run_on_the_fused_kernels(nfa, mode, kind, hidden, K):
         assert f.kernel_name == "rqs2d_h64_mfma"
     f.set_option("hidden_matmul", mode)
     x = O.make_inputs("banana", 5000, seed=len(hidden) + K)
-    ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max() if kind == "rqs" else 0.0
-    assert_close(f.log_prob(x), ref, "padded log_prob", FLOOR * e32)
+    if kind == "rqs":
+        assert_spline_forward(f, spec, x, "padded")
+    else:
+        assert_close(f.log_prob(x), O.log_prob(spec, x), "padded log_prob")
+        z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+        zr, ldr = O.chain_forward(spec, x)
+        assert_close(z, zr, "padded forward")
+        assert_close(ld, ldr, "padded forward logdet")
     assert abs(f.nll(x) - O.nll(spec, x)) <= 1e-5 * max(1.0, abs(O.nll(spec, x)))
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    zr, ldr = O.chain_forward(spec, x)
-    z32, l32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, "padded forward", FLOOR * np.abs(z32 - zr).max() if kind == "rqs" else 0.0)
-    assert_close(ld, ldr, "padded forward logdet", FLOOR * np.abs(l32 - ldr).max() if kind == "rqs" else 0.0)
     # the caller's weights come back in the caller's layout
     got = f.get_weights()
     for l in range(8):
@@ -697,15 +730,15 @@ def test_general_path_small_batches_split_k(nfa, monkeypatch, kind, D, hidden, r
         make = lambda: rqs_flow(nfa, spec)
     x = (np.random.default_rng(D + rows).standard_normal((rows, D)) * 1.5).astype(np.float32)
     ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
+    lp32 = O.log_prob(spec, x, np.float32)
     f = make()
     assert f.kernel_name == "generic_gemm"
     got = f.log_prob(x)
-    assert_close(got, ref, "split-K log_prob", FLOOR * e32)
+    assert_spline_close(got, ref, lp32, "split-K log_prob")
     monkeypatch.setenv("NF_NO_SPLITK", "1")
     whole = make().log_prob(x)
-    assert_close(whole, ref, "whole-K log_prob", FLOOR * e32)
-    assert np.abs(whole.astype(np.float64) - got).max() <= 2 * max(FLOOR * e32, float(tol(ref).max()))
+    assert_spline_close(whole, ref, lp32, "whole-K log_prob")
+    assert (np.abs(whole.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(lp32 - ref))).all()
 
 
 # ------------------------------------------------------------------ backward pass / training step
