@@ -10,15 +10,25 @@ every step costs the chain kernel ~10 % (measured), one per batch of steps nothi
 
     python bench.py --gpus N --steps K --warmup W
 
+Timing: W untimed warm-up steps, then BLOCKS of exactly K steps, each bracketed by a
+barrier + device synchronise on both sides, wall time = max over ranks.  One block
+of K = 20 steps is 11 ms -- a single draw of a kernel whose own duration scatters
+by +-8 % from launch to launch -- so blocks are repeated until >= 0.5 s of them have run
+(at most 200); `value` / `ms_per_step` are the MEDIAN block's, `block_ms` carries
+min / median / max and the count.
+
 N > 1 is launched by `python -m torch.distributed.run`; torch.distributed (gloo,
 CPU) is used only for the rendezvous, the barrier and the max-over-ranks of the
 timing.  All GPU work goes through libnf_hip.so (own stream, own RCCL
 communicator); torch never touches the device.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the contract keys for the headline (BASELINE.json
+configs[1]/[3]: 8 affine layers, banana, 2^20 rows per GPU) + `roofline` +
+`cpu_baseline`, and at N = 1 `other_configs`: configs[0], [2] and [4] timed the same way.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,23 +40,27 @@ sys.path.insert(0, ROOT)
 
 # measured/spec constants: /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, spec (155 measured)
-FLOP_PER_EVAL_L8 = 69632       # L * 2 * (2*64 + 64*64 + 64*2), L = 8
 BYTES_PER_EVAL = 12            # 8 B in (x[2] f32) + 4 B out (log_prob f32)
+# algorithmic (useful) FLOP per eval, SURVEY.md 8(d)
+FLOP_AFFINE_PER_LAYER = 2 * (2 * 64 + 64 * 64 + 64 * 2)           # 8,704
+FLOP_RQS12_PER_LAYER = 2 * (2 * 64 + 64 * 64 + 64 * 37)           # 13,184: the 37 parameters of the transformed dim
+FLOP_MNIST_PER_LAYER = 2 * (784 * 512 + 2 * 512 * 512 + 512 * 9800)  # 11,886,592: only the 392 transformed pixels
 
 
-def profiled_traffic(kernel_prefix="void nf::affine2d::chain_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
-    command (profiles/collect_r01.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
+def profiled_traffic(kernel_prefix, summary_name):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this command
+    (profiles/collect_r02.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
     MI355X_MICROARCH.md prescribes and profiles/calibrate_fetch.py confirms).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "final_bench_n1_pmc_summary.json")
-    try:
-        summary = json.load(open(path))
-        for name, counters in summary.items():
-            if name.startswith(kernel_prefix) and counters.get("hbm_bytes_per_launch"):
-                return float(counters["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, summary_name)
+        try:
+            summary = json.load(open(path))
+            for name, counters in summary.items():
+                if name.startswith(kernel_prefix) and counters.get("hbm_bytes_per_launch"):
+                    return float(counters["hbm_bytes_per_launch"]), f"profiles/{rnd}/{summary_name}"
+        except Exception:
+            pass
+    return None, None
 
 
 def usable_cpus():
@@ -61,29 +75,45 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(layers, density):
-    """The C restatement of the oracle (oracle/nf_oracle.c, OpenMP over the batch) timed on
-    this host's cores: a reported baseline ("port"), not the target.  Bounded sample of the
-    same workload (about 10 s).  The ONLY place this file touches oracle/."""
+def cpu_baseline(layers, layers4, density):
+    """The oracle timed on this host's cores: a reported baseline ("port"), not the target.  Bounded samples of
+    the same workloads (about 20 s in all).  The ONLY place this file touches oracle/.
+      value:  C/OpenMP restatement (oracle/nf_oracle.c) on the headline (2^20 rows, 8 layers);
+      others: the same C port at BASELINE configs[0] (4096 rows, 4 layers -- the reference's own CPU-runnable
+              case, src/real_nvp_toy_densities.py:139-151) and the NumPy float32 restatement (oracle/flows_np.py,
+              BLAS threads as the host gives them) on the headline batch."""
     from oracle import c_oracle as CO
     from oracle import flows_np as O
     spec = O.FlowSpec("affine", 2, layers, O.alternating_masks(2, len(layers), 1))
+    spec4 = O.FlowSpec("affine", 2, layers4, O.alternating_masks(2, len(layers4), 1))
     rows = 1 << 20
     x = O.make_inputs(density, rows)
     threads = min(CO.max_threads(), usable_cpus())
     CO.affine_masked_log_prob(spec, x[:1 << 16], threads)  # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        CO.affine_masked_log_prob(spec, x, threads)
-        reps += 1
-        if time.perf_counter() - t0 > 10.0:
-            break
-    dt = time.perf_counter() - t0
+
+    def timed(fn, budget):
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            fn()
+            reps += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        return reps, time.perf_counter() - t0
+
+    reps, dt = timed(lambda: CO.affine_masked_log_prob(spec, x, threads), 10.0)
+    x4k = x[:4096]
+    reps4, dt4 = timed(lambda: CO.affine_masked_log_prob(spec4, x4k, threads), 3.0)
+    reps_np, dt_np = timed(lambda: O.log_prob(spec, x, np.float32), 4.0)
     return {"value": rows * reps / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": f"C/OpenMP float32 restatement (oracle/nf_oracle.c), {reps} x 2^20 rows of the same "
                       f"{len(spec.layers)}-layer flow on {density}, {threads} OpenMP threads "
-                      f"(host reports {os.cpu_count()} logical CPUs)"}
+                      f"(host reports {os.cpu_count()} logical CPUs)",
+            "others": [
+                {"what": "C/OpenMP port at BASELINE configs[0]: 4 layers, 4096 rows per call", "value": 4096 * reps4 / dt4,
+                 "unit": "evals/s", "cores": int(threads), "ms_per_call": dt4 / reps4 * 1e3, "calls": reps4},
+                {"what": "NumPy float32 restatement (oracle/flows_np.py), headline batch 2^20 x 8 layers",
+                 "value": rows * reps_np / dt_np, "unit": "evals/s", "cores": usable_cpus(), "calls": reps_np}]}
 
 
 def main():
@@ -94,10 +124,12 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU (weak scaling)")
     ap.add_argument("--density", default="banana")
     ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step block until this much of it has run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hidden-matmul", default="f32", choices=["f32", "bf16x3"],
                     help="nf_flow_set_option hidden_matmul for the timed steps (default: exact float32 MFMA)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra bf16x3 timing after the run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[0], [2], [4] (N = 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,16 +158,57 @@ def main():
         import torch.distributed as dist  # gloo: CPU-side rendezvous only
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from normalizing_flows_amd import sharding
-        import torch
         try:
+            # every step that can fail on one rank alone (device, librccl, the id, the init itself) is agreed on
+            # over gloo inside; a failure raises RanksDisagree on EVERY rank -- nobody is left inside ncclCommInitRank
             comm = sharding.RcclComm.from_torch_distributed(dist)
-        except Exception as exc:   # keep measuring: the per-rank partial NLLs are then summed over gloo at the end
-            comm, rccl_error = None, f"{type(exc).__name__}: {exc}"
-        ok = torch.tensor([1 if comm is not None else 0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 0 and comm is not None:
-            comm.close()
-            comm, rccl_error = None, "another rank failed to initialise RCCL"
+        except sharding.RanksDisagree as exc:
+            # keep measuring: the per-rank partial NLLs are then summed over gloo at the end (the JSON line says so)
+            comm, rccl_error = None, str(exc)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(*vals):
+        if dist is None:
+            return vals
+        import torch
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
+    def measure(f, step, steps, warmup, min_seconds):
+        """`step(i)` enqueues one pass on handle f.  Returns (median block wall s, its event ms, all walls)."""
+        for i in range(warmup):
+            step(i)
+        f.synchronize()
+        _lib.check(lib.nf_device_synchronize())
+
+        def block():
+            barrier()
+            t0 = time.perf_counter()
+            f.timer_start()
+            for i in range(steps):
+                step(i)
+            ev = f.timer_stop()          # HIP events on the stream the kernels ran on
+            f.synchronize()              # N > 1: the one all-reduce over the K steps' NLL sums runs here, inside the clock
+            _lib.check(lib.nf_device_synchronize())
+            w = time.perf_counter() - t0  # this rank's K steps, device idle again; MAX over ranks below
+            barrier()
+            return max_over_ranks(w, ev)
+
+        blocks = [block()]
+        # the same count on every rank: the first block's wall is already the max over ranks
+        n = max(1, min(200, int(math.ceil(min_seconds / max(blocks[0][0], 1e-6)))))
+        blocks += [block() for _ in range(n - 1)]
+        walls = sorted(b[0] for b in blocks)
+        med = sorted(blocks)[len(blocks) // 2]
+        return med[0], med[1], walls
+
+    def block_stats(walls, steps):
+        return {"n": len(walls), "min": walls[0] * 1e3 / steps, "median": walls[len(walls) // 2] * 1e3 / steps,
+                "max": walls[-1] * 1e3 / steps, "unit": "ms per step, per block of K steps"}
 
     # synthetic weights (random init of the architecture: haiku's truncated-normal hidden layers, a small
     # non-zero last Linear so that the flow is not the identity), the same on every rank
@@ -154,49 +227,44 @@ def main():
     xd = next(densities.get_density(args.density)(seed=2123 + rank, batch_size=rows, num_batches=1, device=True))
     lpd = flow.DeviceArray((rows,))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def headline_step(i):
+        f.nll_enqueue(xd, rows_global, i % _lib.NF_NLL_SLOTS, lpd)
 
-    def timed_run():
-        """W warmup steps, then exactly K steps between barrier + device synchronize; max over ranks."""
-        for i in range(args.warmup):
-            f.nll_enqueue(xd, rows_global, i % _lib.NF_NLL_SLOTS, lpd)
-        f.synchronize()
-        _lib.check(lib.nf_device_synchronize())
-        barrier()
-        t0 = time.perf_counter()
-        f.timer_start()
-        for i in range(args.steps):
-            f.nll_enqueue(xd, rows_global, i % _lib.NF_NLL_SLOTS, lpd)
-        ev = f.timer_stop()          # HIP events on the stream the kernels ran on
-        f.synchronize()              # N > 1: the one all-reduce over the K steps' NLL sums runs here, inside the clock
-        _lib.check(lib.nf_device_synchronize())
-        w = time.perf_counter() - t0  # this rank's K steps, device idle again; MAX over ranks below
-        barrier()
+    def headline_run():
+        wall, ev_ms, walls = measure(f, headline_step, args.steps, args.warmup, args.min_seconds)
         result = f.nll_result((args.steps - 1) % _lib.NF_NLL_SLOTS)
-        if dist is not None:
+        if dist is not None and comm is None and world > 1:   # RCCL fallback: ranks hold partial means
             import torch
-            t = torch.tensor([w, ev], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            w, ev = float(t[0]), float(t[1])
-            if comm is None and world > 1:   # RCCL fallback: ranks hold partial means of the global batch
-                r = torch.tensor([result], dtype=torch.float64)
-                dist.all_reduce(r, op=dist.ReduceOp.SUM)
-                result = float(r[0])
-        return w, ev, result
+            r = torch.tensor([result], dtype=torch.float64)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            result = float(r[0])
+        return wall, ev_ms, walls, result
 
-    wall, ev_ms, nll = timed_run()
+    wall, ev_ms, walls, nll = headline_run()
     variant = None
     if args.hidden_matmul == "f32" and not args.no_variants:
         # the same steps once more under the optional split-bf16 hidden matmul (same tolerance
         # against the oracle, tests/test_bf16x3_gpu.py); reported beside the headline, never as it
         f.set_option("hidden_matmul", "bf16x3")
-        v_wall, v_ev, v_nll = timed_run()
+        v_wall, v_ev, v_walls, v_nll = headline_run()
         f.set_option("hidden_matmul", "f32")
         variant = {"hidden_matmul": "bf16x3", "value": rows_global * args.steps / v_wall, "unit": "evals/s",
                    "ms_per_step": v_wall * 1e3 / args.steps, "kernel_ms": v_ev / args.steps, "nll": v_nll,
-                   "nll_minus_headline_nll": v_nll - nll}
+                   "nll_minus_headline_nll": v_nll - nll, "block_ms": block_stats(v_walls, args.steps)}
+
+    # every rank must have issued the same number of collectives by now (one batched all-reduce per block and
+    # result): a rank that skipped one would deadlock the NEXT collective -- say so instead
+    coll_error = None
+    if dist is not None and world > 1:
+        from normalizing_flows_amd import sharding
+        try:
+            sharding.agree_equal(dist, f.collective_count(), "collectives issued by the headline handle")
+        except sharding.RanksDisagree as exc:
+            coll_error = str(exc)
+
+    other = []
+    if world == 1 and not args.no_other_configs and args.hidden_matmul == "f32":
+        other = other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, block_stats)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -204,8 +272,9 @@ def main():
         # dominant kernel: the fused chain; its launch duration ~ event time per step
         # (the 1-block sum kernel and the 8-byte copy are < 1 % of it)
         kern_s = ev_ms * 1e-3 / args.steps
-        flop_per_eval = FLOP_PER_EVAL_L8 * args.layers / 8
+        flop_per_eval = FLOP_AFFINE_PER_LAYER * args.layers
         achieved_tflops = rows * flop_per_eval / kern_s / 1e12
+        traffic, traffic_src = profiled_traffic("void nf::affine2d::chain_kernel", "final_bench_n1_pmc_summary.json")
         out = {
             "metric": "log_prob evals/sec (batch=2^20 per GPU)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -219,11 +288,12 @@ def main():
                                       if rccl_error is None else
                                       f"dp{world} (batch rows sharded; RCCL unavailable -- {rccl_error} -- so the "
                                       "per-rank partial NLLs were summed over gloo after the timed steps)"},
+            "block_ms": block_stats(walls, args.steps),
             "nll": nll,
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": profiled_traffic() if (rows == 1 << 20 and args.layers == 8) else None,
-                         "traffic_unit": "bytes of HBM per launch (rocprofv3 PMC, profiles/r01); algorithmic "
+                         "traffic": traffic if (rows == 1 << 20 and args.layers == 8) else None,
+                         "traffic_unit": f"bytes of HBM per launch (rocprofv3 PMC, {traffic_src}); algorithmic "
                                          f"{rows * BYTES_PER_EVAL}",
                          "hbm_algorithmic_GBps": rows * BYTES_PER_EVAL / kern_s / 1e9,
                          "kernel_ms": kern_s * 1e3},
@@ -237,13 +307,80 @@ def main():
                                             f"equivalent rate is {achieved_tflops:.1f} TFLOP/s"})
         if variant is not None:
             out["variants"] = [variant]
+        if other:
+            out["other_configs"] = other
+        if coll_error is not None:
+            out["error"] = coll_error
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(layers, args.density)
+            layers4 = [make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(534 + l), final_std=0.02).linears
+                       for l in range(4)]
+            out["cpu_baseline"] = cpu_baseline(layers, layers4, args.density)
         print(json.dumps(out))
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if coll_error is not None:
+        sys.exit(f"bench.py: {coll_error}")
+
+
+def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, block_stats):
+    """BASELINE.json configs[0], [2] and [4] on this GPU, timed like the headline (blocks of steps, median),
+    each with its useful-FLOP roofline.  Synthetic weights of the architecture, inputs resident in HBM."""
+    res = []
+
+    def run(name, cfg, layers, xd, rows, steps, flop_per_eval, note, dominant=None):
+        f = flow.CouplingFlow(cfg, layers)
+        lpd = flow.DeviceArray((rows,))
+        step = lambda i: f.nll_enqueue(xd, rows, i % _lib.NF_NLL_SLOTS, lpd)  # noqa: E731
+        wall, ev_ms, walls = measure(f, step, steps, max(2, min(args.warmup, steps)), args.min_seconds)
+        nll = f.nll_result((steps - 1) % _lib.NF_NLL_SLOTS)
+        kern_s = ev_ms * 1e-3 / steps
+        tf = rows * flop_per_eval / kern_s / 1e12
+        res.append({"config": name, "kernel": f.kernel_name, "rows": rows, "steps": steps,
+                    "value": rows * steps / wall, "unit": "evals/s", "ms_per_step": wall * 1e3 / steps,
+                    "kernel_ms": kern_s * 1e3, "block_ms": block_stats(walls, steps), "nll": nll,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / PEAK_F32_MFMA_TFLOPS, "flop_per_eval_useful": flop_per_eval,
+                                 "note": note}})
+        if dominant is not None:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+            traffic, src = profiled_traffic(*dominant)
+            res[-1]["roofline"].update({"traffic": traffic, "traffic_unit": f"bytes of HBM per launch of {dominant[0]} "
+                                                                            f"(rocprofv3 PMC, {src})"})
+        f.close()
+
+    # configs[0]: 4 affine layers, banana, 4096 rows (the reference's CPU-runnable case; latency-bound on a GPU)
+    layers = [make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(534 + l), final_std=0.02).linears
+              for l in range(4)]
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=4, hidden=(64, 64))
+    xd = next(densities.get_density("banana")(seed=2123, batch_size=4096, num_batches=1, device=True))
+    run("configs[0]: RealNVP 4 affine layers, banana, batch=4096", cfg, layers, xd, 4096, max(args.steps, 200),
+        4 * FLOP_AFFINE_PER_LAYER, "16 of the chip's 1024 SIMDs hold a tile: latency-bound, not a roofline case")
+    # configs[2]: spline coupling ("MAF" in the reference), 8 layers, K = 12 on [-8, 8], gaussian_blobs, 2^20 rows
+    layers = [make_conditioner((2,), [64, 64], 37, per_dim=True, rng=np.random.default_rng(534 + l),
+                               final_std=0.05).linears for l in range(8)]
+    cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), rqs_bins=12,
+                          rqs_range_min=-8.0, rqs_range_max=8.0)
+    xd = next(densities.get_density("gaussian_blobs")(seed=2123, batch_size=1 << 20, num_batches=1, device=True))
+    run("configs[2]: spline coupling (maf_toy_densities.py) 8 layers K=12, gaussian_blobs, batch=2^20", cfg, layers,
+        xd, 1 << 20, args.steps, 8 * FLOP_RQS12_PER_LAYER,
+        "useful FLOP = the 37 spline parameters of the transformed dim; the kernel computes 26 of them on the MFMA "
+        "and the 2 slope logits of the sample's bin on the VALU",
+        dominant=("void nf::rqs2d::chain_kernel", "config_c_pmc_summary.json"))
+    del xd
+    # configs[4]: MNIST shape, 6 layers, 784-D, MLP 512x3, K = 8 on [0, 1], Uniform base, 2^16 rows
+    layers = [make_conditioner((784,), [512, 512, 512], 25, per_dim=True, rng=np.random.default_rng(534 + l),
+                               final_std=0.05).linears for l in range(6)]
+    cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=784, num_layers=6, hidden=(512, 512, 512), rqs_bins=8,
+                          rqs_range_min=0.0, rqs_range_max=1.0, base=_lib.BASE_UNIFORM01)
+    rows = 1 << 16
+    x = (np.random.default_rng(2123).integers(0, 256, (rows, 784)) / 256.0).astype(np.float32)  # prepare_data's k / 256
+    xd = flow.DeviceArray.from_numpy(x)
+    run("configs[4]: spline coupling (maf_mnist.py) 6 layers, 784-D, MLP 512x3, K=8, batch=2^16", cfg, layers, xd, rows,
+        max(2, min(args.steps, 5)), 6 * FLOP_MNIST_PER_LAYER,
+        "whole call (4 GEMMs + spline epilogue per layer); useful FLOP = transformed pixels' columns only",
+        dominant=("void nf::generic::gemm_rqs_kernel", "config_d_pmc_summary.json"))
+    return res
 
 
 if __name__ == "__main__":

@@ -156,13 +156,17 @@ int nf_flow_synchronize(nf_flow* flow);
                        fused spline kernel (both of its Linears) and the general path
                        (every Linear with K >= 32 and N >= 64); NF_ERR_UNSUPPORTED on the
                        split2d kernel, which has no MFMA.
-   Applies to every later chain walk of the handle (log_prob, nll, sample, chain_apply,
-   the forward half of nf_nll_grad keeps float32).
+   Applies to every later chain walk of the handle (log_prob, nll, sample, chain_apply).  The
+   forward half of nf_nll_grad / nf_train_step on the fused kernels keeps the float32 kernels
+   (the bf16x3 weight image is packed on the host; refreshing it after every optimiser step
+   would cost a synchronise and two copies per step); the fused affine backward follows the
+   mode for the two products that feed other products.
      "skip_nonfinite_updates" = "0" (default) | "1"
        "1": optax.apply_if_finite around nf_train_step's optimiser -- a step whose gradient
             holds a NaN or an infinity (one far outlier is enough for an unconstrained
-            exp(log_scale) flow in float32) leaves weights and moments as they are; the loss
-            returned is still the non-finite one.  "0" is what the reference's unwrapped
+            exp(log_scale) flow in float32) leaves weights and moments as they are, and Adam's
+            step count (its bias correction) advances only on applied steps, as the wrapped
+            optimiser's own count does; the loss returned is still the non-finite one.  "0" is what the reference's unwrapped
             optax.adam / sgd_update do: every weight becomes NaN. */
 int nf_flow_set_option(nf_flow* flow, const char* name, const char* value);
 int nf_flow_get_option(const nf_flow* flow, const char* name, char* buf, size_t buf_len);

@@ -341,7 +341,23 @@ class Chain(Bijector):
                              first_mask_parity=first.parity, base=base, rqs_bins=rqs[0],
                              rqs_range_min=rqs[1], rqs_range_max=rqs[2], rqs_min_bin_size=rqs[3],
                              rqs_min_knot_slope=rqs[4])
-            if cached is not None:
+            from . import haiku_like
+            frame = haiku_like.current_frame()
+            if frame is not None and frame.mode == "apply":
+                # built inside haiku_like's apply(params, ...): this Chain object lives for one call, the device
+                # handle is kept by the transformed function for as long as `params` keeps its values
+                slot = (cfg, tuple(b._perm for b in layers))
+                held = frame.owner.flow_cache.get(slot)
+                if held is None:
+                    held = (frame.params_key, CouplingFlow(cfg, [b.packed_linears() for b in layers]))
+                elif held[0] != frame.params_key:
+                    held[1].set_weights([b.packed_linears() for b in layers])
+                    held = (frame.params_key, held[1])
+                frame.owner.flow_cache[slot] = held
+                self._flows[base] = (key, held[1])
+                self._borrowed = True
+                return held[1], first.event_shape
+            if cached is not None and not getattr(self, "_borrowed", False):
                 cached[1].close()
             cached = (key, CouplingFlow(cfg, [b.packed_linears() for b in layers]))
             self._flows[base] = cached

@@ -99,13 +99,29 @@ def make_conditioner(event_shape: Sequence[int], hidden_sizes: Sequence[int], nu
     b = 0; final Linear zeros (final_std > 0 draws N(0, final_std^2) instead, for tests
     and benchmarks that need a non-identity flow).
     """
-    rng = rng if rng is not None else np.random.default_rng(42)
     d = int(np.prod(event_shape))
     sizes = [d, *[int(h) for h in hidden_sizes]]
+    n_out = d * num_bijector_params if per_dim else num_bijector_params
+    from . import haiku_like
+    frame = haiku_like.current_frame()
+    if frame is not None:
+        # inside haiku_like.transform: parameters are created (init) or taken from the params dict (apply) under
+        # haiku's module names, in creation order -- what the reference's hk.Sequential does
+        def hidden(r, fi, fo):
+            return _trunc_normal(r, (fi, fo), 1.0 / math.sqrt(fi)), np.zeros(fo, np.float32)
+
+        def final(r, fi, fo):
+            if final_std > 0:
+                return ((r.standard_normal((fi, fo)) * final_std).astype(np.float32),
+                        (r.standard_normal(fo) * final_std).astype(np.float32))
+            return np.zeros((fi, fo), np.float32), np.zeros(fo, np.float32)
+        shapes = list(zip(sizes, sizes[1:] + [n_out]))
+        lin = haiku_like.conditioner_params(frame, shapes, hidden, final)
+        return MLPConditioner(lin, "relu", event_shape, num_bijector_params if per_dim else None)
+    rng = rng if rng is not None else np.random.default_rng(42)
     lin: List[LinearParams] = []
     for fi, fo in zip(sizes[:-1], sizes[1:]):
         lin.append((_trunc_normal(rng, (fi, fo), 1.0 / math.sqrt(fi)), np.zeros(fo, np.float32)))
-    n_out = d * num_bijector_params if per_dim else num_bijector_params
     if final_std > 0:
         W = (rng.standard_normal((sizes[-1], n_out)) * final_std).astype(np.float32)
         b = (rng.standard_normal(n_out) * final_std).astype(np.float32)

@@ -168,6 +168,7 @@ struct nf_flow {
   double* d_block_sums = nullptr;
   double* d_sum = nullptr;
   double* h_ring = nullptr;  // pinned, NF_NLL_SLOTS
+  double* h_ring_dev = nullptr;  // the same memory as the device sees it (hipHostGetDevicePointer), or null
   long long ring_rows[NF_NLL_SLOTS];
   nf_comm* comm = nullptr;
   // Every collective this handle issues goes through flow_allreduce_*: one communicator serves both streams
@@ -185,6 +186,9 @@ struct nf_flow {
 };
 
 static int get_weights_internal(nf_flow* f, float* packed, size_t count);  // the handle's own (padded) layout
+
+// nf_nll_enqueue: at most this many rows keep the NLL tail on the handle's main stream (see there)
+constexpr long long kInlineTailRows = 1 << 16;
 
 namespace nf {
 
@@ -253,11 +257,14 @@ static int run_chain_plan(nf_flow* f, const ChainIO& io, int* out_grid);
 static int refresh_rqs_image(nf_flow* f);
 
 // Enqueue a chain walk on device pointers.  out_grid = number of block sums written.
-static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid) {
+// allow_x3 = false: the float32 kernels whatever the handle's matmul mode (the forward half of the training step:
+// the bf16x3 image is packed on the host, so refreshing it after every optimiser step would cost a synchronise and
+// two copies per step; include/nf_hip.h documents that this walk keeps float32).
+static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid, bool allow_x3 = true) {
   ChainIO io = io_in;
   io.base = f->desc.base;
   if (f->path == PATH_RQS2D_H64 && f->wimg_stale) NF_TRY(refresh_rqs_image(f));
-  if (f->x3 && (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64)) {
+  if (allow_x3 && f->x3 && (f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64)) {
     if (f->x3_stale) NF_TRY(refresh_x3_image(f));
     if (f->path == PATH_RQS2D_H64) return rqs2d_x3::launch(f->d_wimg_x3, f->desc, io, f->stream, out_grid);
     return affine2d_x3::launch(f->d_wimg_x3, f->desc.first_mask_parity, io, f->stream, out_grid);
@@ -543,6 +550,10 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
       s = hip_fail(e, "flow resources", __FILE__, __LINE__);
       break;
     }
+    // the ring as the device addresses it (mapped, coherent host memory); without it the tail copies 8 bytes
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, f->h_ring, 0) == hipSuccess) f->h_ring_dev = static_cast<double*>(dev);
+    else (void)hipGetLastError();
   } while (0);
   for (int q = 0; s == NF_OK && q < NF_NLL_SLOTS; ++q) {
     hipError_t e;
@@ -827,12 +838,25 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   double* sums = f->d_block_sums + (size_t)slot * 4096;
   // the slot's previous tail must have read its block sums before this kernel rewrites them
   if (f->tail_pending[slot]) NF_HIP(hipStreamWaitEvent(f->stream, f->ev_tail[slot], 0));
+  // Small batches (the reference evaluates 128 ... 4096 rows per call): the chain kernel takes ~15 us, less than the
+  // two event records and two stream waits that move the tail to the side stream cost the host -- the step was
+  // API-bound at 36 us.  There the sum kernel follows on the same stream and writes the scalar into the pinned ring:
+  // two launches, nothing else.
+  if (f->comm == nullptr && f->h_ring_dev != nullptr && rows_local > 0 && rows_local <= kInlineTailRows) {
+    NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, sums, &grid));
+    NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->stream, f->h_ring_dev + slot));
+    f->tail_pending[slot] = false;
+    f->ring_rows[slot] = rows_global;
+    return NF_OK;
+  }
   if (rows_local > 0)
     NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, sums, &grid));
   NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));
   NF_HIP(hipStreamWaitEvent(f->side, f->ev_kernel[slot], 0));
+  // without a communicator the sum kernel writes the scalar into the pinned ring itself (h_ring_dev)
+  const bool direct = f->comm == nullptr && f->h_ring_dev != nullptr && rows_local > 0;
   if (rows_local > 0) {
-    NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->side));
+    NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->side, direct ? f->h_ring_dev + slot : nullptr));
   } else {
     NF_HIP(hipMemsetAsync(f->d_sum + slot, 0, sizeof(double), f->side));
   }
@@ -841,7 +865,7 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
     // when a result is asked for (nf_nll_result / nf_flow_synchronize), not one per enqueued batch --
     // a tiny collective kernel per step costs the chain kernel beside it ~10 % (measured)
     f->reduce_pending |= 1ull << slot;
-  } else {
+  } else if (!direct) {
     NF_HIP(hipMemcpyAsync(f->h_ring + slot, f->d_sum + slot, sizeof(double), hipMemcpyDeviceToHost, f->side));
   }
   NF_HIP(hipEventRecord(f->ev_tail[slot], f->side));
@@ -1148,7 +1172,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
       f->plan.record_tape = false;
       NF_TRY(s);
     } else {
-      NF_TRY(run_chain_device(f, io, &grid));
+      NF_TRY(run_chain_device(f, io, &grid, /*allow_x3=*/false));
     }
   }
   NF_HIP(hipEventRecord(f->ev_kernel[slot], f->stream));

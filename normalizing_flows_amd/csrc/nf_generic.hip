@@ -430,22 +430,23 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, const RqsC
   }
   const double iw = rqsmath::bin_scale(sw, K, c), ih = rqsmath::bin_scale(sh, K, c);
   const double mb = (double)c.min_bin;
-  // walk the bins once, keeping the last one whose left knot on the search axis is <= v (bin 0 when none is)
+  // walk the bins once, keeping the last one whose left knot on the search axis is <= v (bin 0 when none is);
+  // a bin's size is its own float64 width rounded once, not a difference of rounded knots (nf_rqs_math.h)
   double ax = (double)c.range_min, ay = (double)c.range_min;
   float xl = c.range_min, yl = c.range_min;
-  float bxl = 0.f, bxr = 0.f, byl = 0.f, byr = 0.f, raw_l = 0.f, raw_r = 0.f;
+  float bxl = 0.f, bw = 0.f, byl = 0.f, bh = 0.f, raw_l = 0.f, raw_r = 0.f;
   for (int k = 0; k < K; ++k) {
-    ax += __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[k], mw), iw, mb);
-    ay += __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[K + k], mh), ih, mb);
-    const float xr = k == K - 1 ? c.range_max : (float)ax;
-    const float yr = k == K - 1 ? c.range_max : (float)ay;
+    const double wx = k == K - 1 ? (double)c.range_max - ax : __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[k], mw), iw, mb);
+    const double wy = k == K - 1 ? (double)c.range_max - ay : __builtin_fma(rqsmath::bin_exp<NF_RQS_XEXP>(p[K + k], mh), ih, mb);
     if (k == 0 || v >= (inverse ? yl : xl)) {
-      bxl = xl; bxr = xr; byl = yl; byr = yr; raw_l = p[2 * K + k]; raw_r = p[2 * K + k + 1];
+      bxl = xl; bw = (float)wx; byl = yl; bh = (float)wy; raw_l = p[2 * K + k]; raw_r = p[2 * K + k + 1];
     }
-    xl = xr; yl = yr;
+    ax += wx; ay += wy;
+    xl = k == K - 1 ? c.range_max : (float)ax;
+    yl = k == K - 1 ? c.range_max : (float)ay;
   }
-  if (inverse) rqsmath::rqs_map<1, false>(bxl, bxr, byl, byr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
-  else rqsmath::rqs_map<0, false>(bxl, bxr, byl, byr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
+  if (inverse) rqsmath::rqs_map<1, false>(bxl, bw, byl, bh, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
+  else rqsmath::rqs_map<0, false>(bxl, bw, byl, bh, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
 }
 
 // G lanes (power of two <= 64) share one row: each takes transformed dims dt = sub, sub+G, ...

@@ -136,15 +136,16 @@ namespace rqs2d {
 //   * of the K+1 slope logits only the two of the bin that holds the sample are ever used: their columns
 //     are kept in accumulator order (kWS) and each lane gathers the pair of its bin after the bin search
 //     (2 x 32 v_fma + one half-wave add instead of a second 32-row MFMA tile: 2048 MFMA cycles -> 280).
-constexpr int kSlopeStride = 13;       // K + 1 <= 13 slope columns per hidden unit
+constexpr int kSlopePairs = 12;        // K <= 12 bins: K pairs (slope k, slope k+1) per hidden unit
 constexpr int kA2 = 0;                 // [32 kstep][64 lane][2 mtile]   W2 (scaled 2^64)
 constexpr int kA3 = 4096;              // [8 kgroup][64 lane][4 kstep']  bin-size + boundary-slope rows, k in accumulator order
-constexpr int kWS = kA3 + 2048;        // [2 half][32 slot][kSlopeStride] slope columns, hidden units in accumulator order
-constexpr int kW1B1 = kWS + 2 * 32 * kSlopeStride;  // [64 k][2]
+constexpr int kWS = kA3 + 2048;        // [2 half][32 slot][kSlopePairs][2] slope columns k and k+1 side by side (one aligned
+                                       // 8-byte read per hidden unit fetches the pair of bin k), units in accumulator order
+constexpr int kW1B1 = kWS + 2 * 32 * kSlopePairs * 2;  // [64 k][2]
 constexpr int kB2 = kW1B1 + 128;       // [2 half][2 mtile][16 reg]
 constexpr int kB3 = kB2 + 64;          // [2 half][16 slot]               bias of the rows each half owns
-constexpr int kBS = kB3 + 32;          // [kSlopeStride] + pad            bias of the slope logits
-constexpr int kLayerFloats = kBS + 16; // 7216 floats = 28,864 B
+constexpr int kBS = kB3 + 32;          // [kSlopePairs][2]                bias of slope logits k and k+1
+constexpr int kLayerFloats = kBS + 2 * kSlopePairs;  // 7928 floats = 31,712 B
 constexpr int kSlotSlopeFirst = 14, kSlotSlopeLast = 15;
 void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                 const float* b3, int cond_dim, int K, float* image);
@@ -304,7 +305,8 @@ int launch_debug_read_f2(const float* x, long long rows, float* out, hipStream_t
 }  // namespace generic
 
 // ---- float64 fixed-order reduction of per-block sums --------------------------
-int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream);
+int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream,
+                      double* host_out = nullptr);  // host_out: device-mapped pinned slot written by the kernel itself
 
 // ---- RCCL (dlopen'ed) ---------------------------------------------------------
 int comm_allreduce_sum_f64(nf_comm* comm, double* dev_values, size_t count, hipStream_t stream);

@@ -55,35 +55,35 @@ __device__ __forceinline__ f32x16 lds_f32x16(const float* p) {
 using rqsmath::knots_f64;
 using rqsmath::softplus_f;
 
-// The bin that holds v on the search axis (x going forward: half 0; y inversely: half 1) and its knot pair
-// on both axes, identical in both half-waves.  knot[]: this half's axis.
+// The bin that holds v on the search axis (x going forward: half 0; y inversely: half 1), its lower-left knot
+// and its size on both axes, identical in both half-waves.  knot[], size[]: this half's axis.
 template <int K, int INV>
-__device__ __forceinline__ int spline_bin(const float (&knot)[K + 1], float v, int h, float* xl, float* xr,
-                                          float* yl, float* yr) {
+__device__ __forceinline__ int spline_bin(const float (&knot)[K + 1], const float (&size)[K], float v, int h, float* xl,
+                                          float* bw, float* yl, float* bh) {
   int kb = 0;
 #pragma unroll
   for (int k = 1; k < K; ++k) kb += (v >= knot[k]) ? 1 : 0;
   const int kb_other = __float_as_int(swap_halves(__int_as_float(kb)));
   kb = (h == INV) ? kb : kb_other;
-  float lo = knot[0], hi = knot[1];
+  float lo = knot[0], sz = size[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     const bool c = kb >= k;
     lo = c ? knot[k] : lo;
-    hi = c ? knot[k + 1] : hi;
+    sz = c ? size[k] : sz;
   }
-  const float lo_o = swap_halves(lo), hi_o = swap_halves(hi);
-  *xl = h == 0 ? lo : lo_o; *xr = h == 0 ? hi : hi_o;
-  *yl = h == 0 ? lo_o : lo; *yr = h == 0 ? hi_o : hi;
+  const float lo_o = swap_halves(lo), sz_o = swap_halves(sz);
+  *xl = h == 0 ? lo : lo_o; *bw = h == 0 ? sz : sz_o;
+  *yl = h == 0 ? lo_o : lo; *bh = h == 0 ? sz_o : sz;
   return kb;
 }
 
 // the map itself: rqsmath::rqs_map, tails behind a wave-uniform test (every lane of a live wave is here)
 template <int INV>
-__device__ __forceinline__ void spline_map(float xl, float xr, float yl, float yr, float raw_l, float raw_r,
+__device__ __forceinline__ void spline_map(float xl, float bw, float yl, float bh, float raw_l, float raw_r,
                                            float raw_first, float raw_last, float v, const Params& p, float* out,
                                            float* logdet) {
-  rqsmath::rqs_map<INV, true>(xl, xr, yl, yr, raw_l, raw_r, raw_first, raw_last, v, p, out, logdet);
+  rqsmath::rqs_map<INV, true>(xl, bw, yl, bh, raw_l, raw_r, raw_first, raw_last, v, p, out, logdet);
 }
 
 // One spline evaluation with every slope logit at hand (nf_rqs2d_x3.hip).  lg[K]: this half's bin-size
@@ -92,10 +92,10 @@ __device__ __forceinline__ void spline_map(float xl, float xr, float yl, float y
 template <int K, int INV>
 __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K + 1], float v, int h,
                                        const Params& p, float* out, float* logdet) {
-  float knot[K + 1];
-  knots_f64<K, NF_RQS_XEXP>(lg, p, knot);
-  float xl, xr, yl, yr;
-  const int kb = spline_bin<K, INV>(knot, v, h, &xl, &xr, &yl, &yr);
+  float knot[K + 1], size[K];
+  knots_f64<K, NF_RQS_XEXP>(lg, p, knot, size);
+  float xl, bw, yl, bh;
+  const int kb = spline_bin<K, INV>(knot, size, v, h, &xl, &bw, &yl, &bh);
   float sl = sg[0], sr = sg[1];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void spline(const float (&lg)[K], const float (&sg)[K
     sl = c ? sg[k] : sl;
     sr = c ? sg[k + 1] : sr;
   }
-  spline_map<INV>(xl, xr, yl, yr, sl, sr, sg[0], sg[K], v, p, out, logdet);
+  spline_map<INV>(xl, bw, yl, bh, sl, sr, sg[0], sg[K], v, p, out, logdet);
 }
 
 }  // namespace rqs2d

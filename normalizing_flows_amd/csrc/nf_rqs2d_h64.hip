@@ -66,15 +66,17 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
         const int s = m * 16 + r;
         img[kA3 + ((s >> 2) * 64 + lane) * 4 + (s & 3)] = prm >= 0 ? W3[(size_t)j * (2 * P) + dT * P + prm] : 0.f;
       }
-  // slope columns, hidden units in the order a lane of half h holds them (slot = m*16 + r)
+  // slope columns as pairs (k, k+1), hidden units in the order a lane of half h holds them (slot = m*16 + r)
   for (int h = 0; h < 2; ++h)
     for (int m = 0; m < 2; ++m)
       for (int r = 0; r < 16; ++r) {
         const int j = 32 * m + 8 * (r >> 2) + 4 * h + (r & 3);
-        for (int c = 0; c <= K; ++c)
-          img[kWS + (h * 32 + m * 16 + r) * kSlopeStride + c] = W3[(size_t)j * (2 * P) + dT * P + 2 * K + c];
+        for (int c = 0; c < K; ++c)
+          for (int e = 0; e < 2; ++e)
+            img[kWS + ((h * 32 + m * 16 + r) * kSlopePairs + c) * 2 + e] = W3[(size_t)j * (2 * P) + dT * P + 2 * K + c + e];
       }
-  for (int c = 0; c <= K; ++c) img[kBS + c] = b3[dT * P + 2 * K + c];
+  for (int c = 0; c < K; ++c)
+    for (int e = 0; e < 2; ++e) img[kBS + 2 * c + e] = b3[dT * P + 2 * K + c + e];
   for (int k = 0; k < 64; ++k) {
     img[kW1B1 + 2 * k + 0] = ldexpf(W1[cond_dim * 64 + k], -kReluShift);
     img[kW1B1 + 2 * k + 1] = ldexpf(b1[k], -kReluShift);
@@ -220,27 +222,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
 
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        float lg[K], knot[K + 1];
+        float lg[K], knot[K + 1], size[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) lg[k] = out[t][k];
-        knots_f64<K, NF_RQS_XEXP>(lg, p, knot);
-        float xl, xr, yl, yr;
-        const int kb = spline_bin<K, INV>(knot, xt[t], h, &xl, &xr, &yl, &yr);
-        // slope logits kb and kb + 1: this lane's 32 hidden units against the two columns, then the other half's
-        const float* ws = L + kWS + h * (32 * kSlopeStride) + kb;
+        knots_f64<K, NF_RQS_XEXP>(lg, p, knot, size);
+        float xl, bw, yl, bh;
+        const int kb = spline_bin<K, INV>(knot, size, xt[t], h, &xl, &bw, &yl, &bh);
+        // slope logits kb and kb + 1: this lane's 32 hidden units against the column pair of its bin (one aligned
+        // 8-byte LDS read per unit, immediate offsets), then the other half's 32
+        const float2* ws = reinterpret_cast<const float2*>(L + kWS) + h * (32 * kSlopePairs) + kb;
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[t][m][r];
-            d0 = fmaf(v, ws[(m * 16 + r) * kSlopeStride], d0);
-            d1 = fmaf(v, ws[(m * 16 + r) * kSlopeStride + 1], d1);
+            const float2 w = ws[(m * 16 + r) * kSlopePairs];
+            d0 = fmaf(acc[t][m][r], w.x, d0);
+            d1 = fmaf(acc[t][m][r], w.y, d1);
           }
-        const float raw_l = add_halves(d0) + L[kBS + kb];
-        const float raw_r = add_halves(d1) + L[kBS + kb + 1];
+        const float2 bs = reinterpret_cast<const float2*>(L + kBS)[kb];
+        const float raw_l = add_halves(d0) + bs.x;
+        const float raw_r = add_halves(d1) + bs.y;
         float nt, l;
-        spline_map<INV>(xl, xr, yl, yr, raw_l, raw_r, out[t][kSlotSlopeFirst], out[t][kSlotSlopeLast], xt[t], p,
+        spline_map<INV>(xl, bw, yl, bh, raw_l, raw_r, out[t][kSlotSlopeFirst], out[t][kSlotSlopeLast], xt[t], p,
                         &nt, &l);
         ld[t] += l;
         xt[t] = xc[t];

@@ -17,35 +17,35 @@ typedef float f32x16_rqs __attribute__((ext_vector_type(16)));
 template <int K, int INV>
 __device__ __forceinline__ void rqs_eval_reg(const float* __restrict__ p, const RqsConst& c, float v, float* out,
                                              float* logdet) {
-  float lg[K], knot[K + 1];
+  float lg[K], knot[K + 1], size[K];
   // search axis: x (widths) going forward, y (heights) inversely
 #pragma unroll
   for (int k = 0; k < K; ++k) lg[k] = p[(INV ? K : 0) + k];
-  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot);
+  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot, size);
   int kb = 0;
 #pragma unroll
   for (int k = 1; k < K; ++k) kb += (v >= knot[k]) ? 1 : 0;
-  float slo = knot[0], shi = knot[1], raw_l = p[2 * K], raw_r = p[2 * K + 1];
+  float slo = knot[0], ssz = size[0], raw_l = p[2 * K], raw_r = p[2 * K + 1];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     const bool hit = kb >= k;
     slo = hit ? knot[k] : slo;
-    shi = hit ? knot[k + 1] : shi;
+    ssz = hit ? size[k] : ssz;
     raw_l = hit ? p[2 * K + k] : raw_l;
     raw_r = hit ? p[2 * K + k + 1] : raw_r;
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) lg[k] = p[(INV ? 0 : K) + k];
-  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot);
-  float olo = knot[0], ohi = knot[1];
+  rqsmath::knots_f64<K, NF_RQS_XEXP>(lg, c, knot, size);
+  float olo = knot[0], osz = size[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     const bool hit = kb >= k;
     olo = hit ? knot[k] : olo;
-    ohi = hit ? knot[k + 1] : ohi;
+    osz = hit ? size[k] : osz;
   }
-  const float xl = INV ? olo : slo, xr = INV ? ohi : shi, yl = INV ? slo : olo, yr = INV ? shi : ohi;
-  rqsmath::rqs_map<INV, false>(xl, xr, yl, yr, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
+  const float xl = INV ? olo : slo, bw = INV ? osz : ssz, yl = INV ? slo : olo, bh = INV ? ssz : osz;
+  rqsmath::rqs_map<INV, false>(xl, bw, yl, bh, raw_l, raw_r, p[2 * K], p[3 * K], v, c, out, logdet);
 }
 
 constexpr int kCtStride = 129;  // floats per row of the staged result tile (odd: conflict-free column reads)

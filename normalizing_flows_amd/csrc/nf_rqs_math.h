@@ -8,17 +8,21 @@
 // (float32 there: 1e-7 rms) but in the KNOTS -- the softmax normalisation and the running sum put ~1e-7 * 16 of
 // absolute error into every knot: 8e-7 rms, 1e-5 worst, i.e. all of the chain's float32 error.  Knots computed
 // accurately and rounded ONCE to float32 cost 9e-8.  So the bin sizes' sum, the normalisation and the running sum
-// are carried in float64 (gfx950 issues v_fma_f64 / v_add_f64 at the float32 rate; ~60 instructions per axis), the
-// bins' exponentials too (NF_RQS_XEXP: hardware exp2 leaves 2.4e-7 -> 3.8e-7 rms, its ~1 ulp errors differ from bin
-// to bin and do not cancel), the reciprocals get one Newton step and the log-det takes three logarithms instead of
-// one logarithm of a five-factor product.
+// are carried in float64 (gfx950 issues v_fma_f64 / v_add_f64 / v_mul_f64 / v_rndne_f64 / v_ldexp_f64 at the float32
+// rate, conversions at 6 cycles, v_rcp_f64 at 17: profiles/microbench/valu_f64_issue_cost.hip; ~60 instructions per
+// axis), the reciprocals get one Newton step and the log-det takes three logarithms instead of one logarithm of a
+// five-factor product.  The bins' exponentials stay on the hardware exp2 (NF_RQS_XEXP = 0): measured on the GPU
+// (tests/tools/rqs_error_stats.py, configs[2], 16,384 rows per density) float64 exponentials (NF_RQS_XEXP = 1, 14
+// instructions per bin instead of 3) bring the scaled log_prob error from 1.88e-7 to 1.70e-7 rms -- v_exp_f32 is much
+// better than the 1 ulp of noise per bin that costs 3.8e-7 in the NumPy emulation -- and cost 8 % of the fused
+// kernel's time (1.01 -> 1.09 ms at 2^20 rows).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 // 1: the knots' exponentials in float64 (exp_neg_f64, 14 instructions per bin); 0: hardware exp2 (3 per bin).
 #ifndef NF_RQS_XEXP
-#define NF_RQS_XEXP 1
+#define NF_RQS_XEXP 0
 #endif
 
 namespace nf {
@@ -33,10 +37,22 @@ __device__ __forceinline__ float rcp_nr(float b) {
 }
 __device__ __forceinline__ float fast_div(float a, float b) { return a * rcp_nr(b); }
 
-// softplus(v) = max(v, 0) + log(1 + exp(-|v|))
-__device__ __forceinline__ float softplus_f(float v) {
-  return fmaxf(v, 0.f) + fast_log(1.f + fast_exp(-fabsf(v)));
+// log(1 + exp(a)) for a <= 0 with a RELATIVE error of a few 1e-7 down to exp(a) -> 0.  The plain form
+// log(1.f + e) loses e's digits in the sum (absolute error 6e-8: a slope of softplus + min_knot_slope = 1e-4 + 5e-5
+// comes out 4e-4 off, and so does its log in the log-det -- seen on out-of-range inputs of deep chains, where the
+// conditioner sees |x| ~ 30 and emits slope logits of -10).  Below e = 2^-6 the series e - e^2/2 + e^3/3 - e^4/4
+// (truncation e^4/5 relative); above it the hardware log of u = fl(1 + e) plus the first-order term for the part
+// of e that u dropped.
+__device__ __forceinline__ float log1p_exp(float a) {
+  const float e = __builtin_amdgcn_exp2f(a * 1.44269504f);
+  const float u = 1.f + e;
+  const float big = fmaf(e - (u - 1.f), 1.f - e, __builtin_amdgcn_logf(u) * 0.693147181f);
+  const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.333333343f), -0.5f), 1.f);
+  return e < 0.015625f ? small : big;
 }
+
+// softplus(v) = max(v, 0) + log(1 + exp(-|v|))
+__device__ __forceinline__ float softplus_f(float v) { return fmaxf(v, 0.f) + log1p_exp(-fabsf(v)); }
 
 // exp(t), t <= 0, as float64 with ~5e-9 relative error: 2^n * Taylor_7(f ln 2), t log2(e) = n + f, |f| <= 1/2.
 __device__ __forceinline__ double exp_neg_f64(float t) {
@@ -72,8 +88,12 @@ __device__ __forceinline__ double bin_scale(double sum, int K, const C& c) {
 
 // Knots of one axis from its K bin-size logits: softmax * (R - K*min_bin) + min_bin, running sum from
 // range_min, both ends pinned (distrax: padded cumsum).  C: anything with range_min, range_max, min_bin.
+// size[k] is bin k's width rounded from float64 on its own -- NOT knot[k+1] - knot[k]: a bin squeezed to
+// min_bin_size = 1e-4 next to a knot at |x| ~ 5 would come out of that difference 0.5 % wrong (float32 spacing
+// 4.8e-7 there), and so would delta = height / width and 2 log(delta) in the log-det (1e-2 absolute; seen on a
+// sample whose layers park it at the range edge, where NumPy float32 is 2.5e-4 off for the same reason).
 template <int K, int XEXP, class C>
-__device__ __forceinline__ void knots_f64(const float (&lg)[K], const C& c, float (&knot)[K + 1]) {
+__device__ __forceinline__ void knots_f64(const float (&lg)[K], const C& c, float (&knot)[K + 1], float (&size)[K]) {
   float mx = lg[0];
 #pragma unroll
   for (int k = 1; k < K; ++k) mx = fmaxf(mx, lg[k]);
@@ -87,23 +107,25 @@ __device__ __forceinline__ void knots_f64(const float (&lg)[K], const C& c, floa
   knot[0] = c.range_min;
 #pragma unroll
   for (int k = 0; k < K - 1; ++k) {
-    at += __builtin_fma(e[k], scale, mb);
+    const double w = __builtin_fma(e[k], scale, mb);
+    size[k] = (float)w;
+    at += w;
     knot[k + 1] = (float)at;
   }
+  size[K - 1] = (float)((double)c.range_max - at);
   knot[K] = c.range_max;
 }
 
-// The rational-quadratic map on the bin [xl, xr] x [yl, yr] with the bin's two slope logits (raw_l, raw_r)
-// and the boundary slope logits (raw_first, raw_last) for the linear tails.  C: range_min, range_max,
-// slope_offset, min_slope.  WAVE_TAILS: the (rare) tails sit behind a wave-uniform test -- only for callers
-// whose whole wave is active here.
+// The rational-quadratic map on the bin with lower-left knot (xl, yl), width bw and height bh, the bin's two
+// slope logits (raw_l, raw_r) and the boundary slope logits (raw_first, raw_last) for the linear tails.
+// C: range_min, range_max, slope_offset, min_slope.  WAVE_TAILS: the (rare) tails sit behind a wave-uniform
+// test -- only for callers whose whole wave is active here.
 template <int INV, bool WAVE_TAILS, class C>
-__device__ __forceinline__ void rqs_map(float xl, float xr, float yl, float yr, float raw_l, float raw_r,
+__device__ __forceinline__ void rqs_map(float xl, float bw, float yl, float bh, float raw_l, float raw_r,
                                         float raw_first, float raw_last, float v, const C& c, float* out,
                                         float* logdet) {
   const float sl = softplus_f(raw_l + c.slope_offset) + c.min_slope;
   const float sr = softplus_f(raw_r + c.slope_offset) + c.min_slope;
-  const float bw = xr - xl, bh = yr - yl;
   const float rbw = rcp_nr(bw);
   const float delta = bh * rbw;
   const float st = sr + sl - 2.f * delta;

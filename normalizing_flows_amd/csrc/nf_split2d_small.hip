@@ -296,8 +296,11 @@ int launch_bwd_layer(const float* w_layer, int H, int activation, float* v, floa
 // ---------------------------------------------------------------------------
 // fixed-order float64 sum of per-block partial sums -> one scalar
 // ---------------------------------------------------------------------------
+// host_out (may be null): the handle's pinned, device-mapped result slot -- written from the kernel, so that the
+// NLL tail of a step is ONE launch and no 8-byte copy (at the reference's batch sizes the tail, not the chain
+// kernel, sets the step time: 35 -> see profiles/bench_configs.py b4k).
 __global__ __launch_bounds__(256) void sum_blocks_kernel(const double* __restrict__ part, int n,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, double* __restrict__ host_out) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += part[i];
@@ -307,11 +310,17 @@ __global__ __launch_bounds__(256) void sum_blocks_kernel(const double* __restric
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0) {
+    out[0] = red[0];
+    if (host_out != nullptr) {
+      __hip_atomic_store(host_out, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+  }
 }
 
-int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream) {
-  hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, block_sums, n, out_sum);
+int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream, double* host_out) {
+  hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, block_sums, n, out_sum, host_out);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

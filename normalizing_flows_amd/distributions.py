@@ -219,6 +219,14 @@ class Transformed(Distribution):
 
     def log_prob(self, value):
         """x, ildj = bijector.inverse_and_log_det(value); base.log_prob(x) + ildj -- one launch."""
+        from . import haiku_like
+        frame = haiku_like.current_frame()
+        if frame is not None and frame.mode == "init":
+            # hk.transform(...).init: every parameter exists once the model is built; nothing is evaluated
+            _, batch = _flatten_rows(np.asarray(value, np.float32), self.event_shape)
+            return np.zeros(batch, np.float32)
+        if frame is not None:
+            frame.check_all_used()
         flow, direction = self._lowered()
         rows, batch = _flatten_rows(value, self.event_shape)
         lib = _lib.load()
@@ -243,6 +251,10 @@ class Transformed(Distribution):
     def sample(self, *, seed, sample_shape: IntLike = ()):
         """Base draw (Philox4x32-10) and bijector.forward in one device call (nf_sample); identical
         to `bijector.forward(distribution.sample(seed=seed, sample_shape=sample_shape))`."""
+        from . import haiku_like
+        frame = haiku_like.current_frame()
+        if frame is not None and frame.mode == "init":
+            return np.zeros(_as_shape(sample_shape) + self.event_shape, np.float32)
         flow, direction = self._lowered()
         if direction != _lib.DIR_CHAIN_FORWARD:
             return self.bijector.forward(self.distribution.sample(seed=seed, sample_shape=sample_shape))

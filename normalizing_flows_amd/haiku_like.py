@@ -1,0 +1,166 @@
+"""The haiku calls the reference's flow scripts make AROUND the hot path, so that their call sites stay as written:
+
+    @hk.without_apply_rng
+    @hk.transform
+    def log_prob(data):                                        # src/real_nvp_toy_densities.py:113-123
+        model = make_flow_model(event_shape=data.shape[-1:], num_layers=..., hidden_sizes=[...])
+        return model.log_prob(data)
+
+    params = log_prob.init(next(prng_seq), np.zeros((1, *event_shape)))      # :175-177
+    loss = -jnp.mean(log_prob.apply(params, batch))                          # :143,150
+
+`import normalizing_flows_amd.haiku_like as hk` provides `transform`, `without_apply_rng` and `PRNGSequence` with
+those semantics for functions whose only parameterised modules are this package's conditioners
+(`make_conditioner`, which stands for the reference's hk.Sequential([Flatten, hk.nets.MLP, hk.Linear, Reshape])):
+
+  * `init(rng, *args)` runs the function once; every `make_conditioner` call creates its parameters with haiku's
+    initialisers (TruncatedNormal(1/sqrt(fan_in)) weights, zero biases, zero final Linear) and files them under the
+    names haiku gives in creation order -- 'mlp/~/linear_0', ..., 'linear', 'mlp_1/~/linear_0', ..., 'linear_1', ...
+    ('w' [in, out], 'b' [out]) -- and returns that dict.  The function's result is discarded
+    (haiku evaluates it; here nothing is computed: with the zero final Linear the flow is the identity anyway).
+  * `apply(params, [rng,] *args)` runs the function with every `make_conditioner` call taking its parameters from
+    `params` by the same names (ValueError on a missing module or a wrong shape, as haiku raises).
+    The device handles the function's models lower to are kept by the transformed function and reused from call to
+    call while `params` holds the same values, so a loop of `apply` calls costs one kernel launch each, not one
+    handle construction and weight upload each (the reference gets the same from jax.jit's trace cache).
+
+Nothing here computes: evaluation stays in libnf_hip.so.  jax.grad / optax have no counterpart in this module -- the
+training step is `training.update` (nf_train_step), see INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Callable, Dict, List, Mapping, Optional, Tuple
+
+import numpy as np
+
+_FRAMES: List["_Frame"] = []
+
+
+class _Frame:
+    def __init__(self, mode: str, params: Optional[Mapping[str, Mapping[str, np.ndarray]]], rng, owner: "Transformed"):
+        self.mode = mode                  # 'init' | 'apply'
+        self.params = params if mode == "apply" else {}
+        self.rng = rng
+        self.owner = owner
+        self.layer = 0                    # conditioners created so far
+        self.params_key = None
+
+    def check_all_used(self) -> None:
+        """apply: the params dict holds exactly the coupling layers built so far (called when a model is first
+        evaluated, i.e. before anything reaches the GPU, and again when the function returns)."""
+        have = sum(1 for name in self.params if name.startswith("linear"))
+        if self.mode == "apply" and have != self.layer:
+            raise ValueError(f"params hold {have} coupling layers, the function built {self.layer}")
+
+    def next_names(self, n_hidden: int) -> Tuple[List[str], str]:
+        k = self.layer
+        self.layer += 1
+        sfx = "" if k == 0 else f"_{k}"
+        return [f"mlp{sfx}/~/linear_{i}" for i in range(n_hidden)], f"linear{sfx}"
+
+
+def current_frame() -> Optional[_Frame]:
+    return _FRAMES[-1] if _FRAMES else None
+
+
+def _array_key(a: np.ndarray) -> tuple:
+    """Identity + a content check that sees an optimiser step or an in-place edit: the full digest for small
+    arrays, a digest of a strided sample plus both ends for large ones (a 40 MB MNIST Linear is not re-hashed per
+    call; an update that touches less than one element in 4096 of a large array can slip through -- reassign the
+    array instead of editing single entries)."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    if flat.size <= 1 << 16:
+        sample = flat
+    else:
+        sample = np.concatenate([flat[:256], flat[::4096], flat[-256:]])
+    return (id(a), a.shape, str(a.dtype), hashlib.blake2b(np.ascontiguousarray(sample).tobytes(), digest_size=8).digest())
+
+
+def params_key(params: Mapping[str, Mapping[str, np.ndarray]]) -> tuple:
+    return tuple((name, _array_key(mod["w"]), _array_key(mod["b"])) for name, mod in sorted(params.items()))
+
+
+class Transformed:
+    """What hk.transform returns: `.init(rng, *args)` and `.apply(params, rng, *args)`."""
+
+    def __init__(self, fn: Callable, apply_takes_rng: bool = True):
+        self._fn = fn
+        self._apply_takes_rng = apply_takes_rng
+        # (FlowConfig, base) -> (params_key, CouplingFlow): see Chain.lowered
+        self.flow_cache: Dict[tuple, tuple] = {}
+
+    def init(self, rng, *args, **kwargs) -> Dict[str, Dict[str, np.ndarray]]:
+        seed = rng if isinstance(rng, (int, np.integer)) else int(np.asarray(rng).reshape(-1)[-1])
+        frame = _Frame("init", None, np.random.default_rng(seed), self)
+        _FRAMES.append(frame)
+        try:
+            self._fn(*args, **kwargs)
+        finally:
+            _FRAMES.pop()
+        return frame.params
+
+    def apply(self, params, *args, **kwargs):
+        if self._apply_takes_rng:
+            if not args:
+                raise TypeError("apply(params, rng, *args): rng is missing (wrap with without_apply_rng to drop it)")
+            args = args[1:]
+        if not isinstance(params, Mapping):
+            raise ValueError("params must be the dict init() returned (haiku module name -> {'w', 'b'})")
+        frame = _Frame("apply", params, None, self)
+        frame.params_key = params_key(params)
+        _FRAMES.append(frame)
+        try:
+            out = self._fn(*args, **kwargs)
+        finally:
+            _FRAMES.pop()
+        frame.check_all_used()
+        return out
+
+
+def transform(fn: Callable) -> Transformed:
+    """hk.transform."""
+    return Transformed(fn, apply_takes_rng=True)
+
+
+def without_apply_rng(t: Transformed) -> Transformed:
+    """hk.without_apply_rng: `apply(params, *args)`."""
+    out = Transformed(t._fn, apply_takes_rng=False)
+    out.flow_cache = t.flow_cache
+    return out
+
+
+class PRNGSequence:
+    """hk.PRNGSequence(seed): an iterator of keys (here: integers drawn from a seeded generator)."""
+
+    def __init__(self, seed):
+        self._rng = np.random.default_rng(int(seed))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> int:
+        return int(self._rng.integers(0, 2 ** 63 - 1))
+
+
+def conditioner_params(frame: _Frame, shapes: List[Tuple[int, int]], make_hidden, make_final):
+    """Called by make_conditioner under an active frame: the [(W, b), ...] of the next conditioner, created
+    (init) or looked up (apply) under haiku's names."""
+    hidden_names, final_name = frame.next_names(len(shapes) - 1)
+    names = hidden_names + [final_name]
+    out = []
+    for j, (name, (fi, fo)) in enumerate(zip(names, shapes)):
+        if frame.mode == "init":
+            W, b = (make_final if j == len(shapes) - 1 else make_hidden)(frame.rng, fi, fo)
+            frame.params[name] = {"w": W, "b": b}
+        else:
+            mod = frame.params.get(name)
+            if mod is None:
+                raise ValueError(f"params lack module {name!r} (modules are named in creation order: "
+                                 f"'mlp/~/linear_0', ..., 'linear', 'mlp_1/~/linear_0', ...)")
+            W, b = np.asarray(mod["w"]), np.asarray(mod["b"])
+            if W.shape != (fi, fo) or b.shape != (fo,):
+                raise ValueError(f"module {name!r}: expected w {(fi, fo)} and b {(fo,)}, got {W.shape} and {b.shape}")
+        out.append((W, b))
+    return out

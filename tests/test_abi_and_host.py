@@ -140,6 +140,86 @@ def test_conditioner_and_haiku_param_mapping():
             assert np.array_equal(Wa, Wb) and np.array_equal(ba, bb)
 
 
+def _reference_style_log_prob(distrax, hk, num_layers=3, hidden=(64, 64), per_dim_bins=None):
+    """src/real_nvp_toy_densities.py:74-123 with the imports swapped (spline variant: src/maf_toy_densities.py)."""
+    def make_flow_model(event_shape, num_layers, hidden_sizes):
+        mask = np.arange(0, np.prod(event_shape)) % 2
+        mask = np.reshape(mask, event_shape).astype(bool)
+        if per_dim_bins is None:
+            def bijector_fn(params):
+                shift, log_scale = np.split(params, 2, axis=-1)
+                return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+            nparams, per_dim = 2, False
+        else:
+            def bijector_fn(params):
+                return distrax.RationalQuadraticSpline(params, range_min=-8.0, range_max=8.0)
+            nparams, per_dim = 3 * per_dim_bins + 1, True
+        layers = []
+        for _ in range(num_layers):
+            layer = distrax.MaskedCoupling(
+                mask=mask, bijector=bijector_fn,
+                conditioner=distrax.make_conditioner(event_shape, hidden_sizes, nparams, per_dim=per_dim))
+            layers.append(layer)
+            mask = np.logical_not(mask)
+        flow = distrax.Inverse(distrax.Chain(layers))
+        base_distribution = distrax.Independent(
+            distrax.Normal(loc=np.zeros(event_shape), scale=np.ones(event_shape)),
+            reinterpreted_batch_ndims=len(event_shape))
+        return distrax.Transformed(base_distribution, flow)
+
+    @hk.without_apply_rng
+    @hk.transform
+    def log_prob(data):
+        model = make_flow_model(event_shape=data.shape[-1:], num_layers=num_layers, hidden_sizes=list(hidden))
+        return model.log_prob(data)
+
+    return log_prob
+
+
+def test_haiku_like_transform_init_names_and_errors():
+    """hk.transform / without_apply_rng / PRNGSequence around the hot path (src/real_nvp_toy_densities.py:113-123,
+    175-177): init returns haiku's names in creation order with haiku's initialisers; apply checks the tree."""
+    import normalizing_flows_amd as distrax
+    import normalizing_flows_amd.haiku_like as hk
+    log_prob = _reference_style_log_prob(distrax, hk, num_layers=3)
+    prng_seq = hk.PRNGSequence(42)
+    params = log_prob.init(next(prng_seq), np.zeros((1, 2)))
+    assert list(params) == ["mlp/~/linear_0", "mlp/~/linear_1", "linear", "mlp_1/~/linear_0", "mlp_1/~/linear_1",
+                            "linear_1", "mlp_2/~/linear_0", "mlp_2/~/linear_1", "linear_2"]
+    assert params["mlp/~/linear_0"]["w"].shape == (2, 64) and params["mlp_2/~/linear_1"]["w"].shape == (64, 64)
+    assert params["linear_1"]["w"].shape == (64, 2) and params["linear_1"]["b"].shape == (2,)
+    assert np.all(params["linear"]["w"] == 0) and np.all(params["mlp/~/linear_0"]["b"] == 0)   # hk defaults + zeros
+    w = params["mlp_1/~/linear_1"]["w"]
+    assert np.abs(w).max() <= 2 / 8 + 1e-6 and abs(w.std() - 0.88 / 8) < 0.02                  # TruncatedNormal(1/sqrt(64))
+    assert not np.array_equal(params["mlp/~/linear_0"]["w"], params["mlp_1/~/linear_0"]["w"])
+    again = log_prob.init(next(prng_seq), np.zeros((1, 2)))
+    assert not np.array_equal(again["mlp/~/linear_0"]["w"], params["mlp/~/linear_0"]["w"])     # another key
+    assert distrax.layers_from_haiku_params(params)[2][1][0] is not None                         # the loader's names
+    # the spline script's tree: 74 = 2 * 37 outputs per conditioner
+    lp_rqs = _reference_style_log_prob(distrax, hk, num_layers=2, per_dim_bins=12)
+    p2 = lp_rqs.init(7, np.zeros((1, 2)))
+    assert p2["linear_1"]["w"].shape == (64, 74)
+    # apply: missing module, wrong shape, wrong layer count -> ValueError before anything touches the GPU
+    bad = {k: v for k, v in params.items() if k != "linear_1"}
+    with pytest.raises(ValueError):
+        log_prob.apply(bad, np.zeros((4, 2), np.float32))
+    bad = dict(params)
+    bad["mlp_1/~/linear_0"] = {"w": np.zeros((2, 32), np.float32), "b": np.zeros(32, np.float32)}
+    with pytest.raises(ValueError):
+        log_prob.apply(bad, np.zeros((4, 2), np.float32))
+    more = dict(params)
+    more["linear_3"] = params["linear_2"]
+    with pytest.raises(ValueError):
+        log_prob.apply(more, np.zeros((4, 2), np.float32))
+    with pytest.raises(TypeError):
+        hk.transform(lambda d: d).apply(params)       # rng argument missing on the un-wrapped form
+    # the cache key sees an in-place update and a re-assignment, not a no-op
+    k0 = hk.params_key(params)
+    assert hk.params_key(params) == k0
+    params["linear"]["b"][0] = 0.5
+    assert hk.params_key(params) != k0
+
+
 def test_lowering_recognises_reference_structures_without_a_gpu():
     import normalizing_flows_amd as distrax
     from normalizing_flows_amd import _lib

@@ -169,17 +169,20 @@ def test_maf_toy_script(distrax):
     model, layers = make_flow_model_rqs(distrax, (2,), 8, [64, 64], 12, -8.0, 8.0, "normal", rng, 0.05)
     spec = spec_of(layers, "rqs", 2, num_bins=12, range_min=-8.0, range_max=8.0)
     x = O.make_inputs("gaussian_blobs", 4096)
+    from test_parity_gpu import assert_spline_log_prob, sample_noise, spline_ok
     lp = model.log_prob(x)
-    ref = O.log_prob(spec, x)
-    # spline chains amplify float32 rounding: allow 4x the float32 restatement's own worst error
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert (np.abs(lp - ref) <= np.maximum(tol(ref), 4 * e32)).all()
+    # per-sample bound of the spline tests (test_parity_gpu.SPLINE_F32_FACTOR): no batch-wide floor
+    ref = assert_spline_log_prob(lp, spec, x, "maf_toy log_prob")
     assert abs(model.nll(x) - O.nll(spec, x)) <= 1e-5 * max(1.0, abs(O.nll(spec, x)))
     s = model.sample(seed=11, sample_shape=500)
     z = O.base_sample("normal", 500, 2, 11)
     sr = O.sample_from_z(spec, z)
-    e32 = np.abs(O.sample_from_z(spec, z.astype(np.float32), np.float32) - sr).max()
-    assert (np.abs(s - sr) <= np.maximum(2 * tol(sr), 4 * e32)).all()
+    # the generative walk is the ill-conditioned direction: forward error per sample, or backward error
+    # (the float64 density walk of the returned sample lands on z)
+    fwd_ok = spline_ok(s, sr, sample_noise(spec, z)).all(axis=-1)
+    zb, _ = O.chain_forward(spec, s)
+    bwd_ok = (np.abs(zb - z) <= tol(z)).all(axis=-1)
+    assert (fwd_ok | bwd_ok).all()
 
 
 def test_maf_mnist_script_shapes(distrax):
@@ -239,8 +242,10 @@ def test_mnist_shape_sampling(distrax):
     assert s.shape == (48, 28, 28, 1)
     z = O.base_sample("uniform01", 48, 784, 21)
     sr = O.sample_from_z(spec, z)
-    e32 = np.abs(O.sample_from_z(spec, z.astype(np.float32), np.float32) - sr).max()
-    assert (np.abs(s.reshape(48, 784) - sr) <= np.maximum(tol(sr), 4 * e32)).all()
+    from test_parity_gpu import sample_noise, spline_ok
+    fwd_ok = spline_ok(s.reshape(48, 784), sr, sample_noise(spec, z)).all(axis=-1)
+    zb, _ = O.chain_forward(spec, s.reshape(48, 784))
+    assert (fwd_ok | (np.abs(zb - z) <= tol(z)).all(axis=-1)).all()
 
 
 def test_density_generators_on_device(distrax):

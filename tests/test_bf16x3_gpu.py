@@ -274,8 +274,7 @@ def test_x3_rqs_every_instantiation(nfa, monkeypatch, tune):
     f = rqs_flow(nfa, spec)
     f.set_option("hidden_matmul", "bf16x3")
     x = O.make_inputs("gaussian_blobs", 1 << 17, seed=9)
-    ref = O.log_prob(spec, x)
-    P.assert_spline_close(f.log_prob(x), ref, O.log_prob(spec, x, np.float32), f"rqs bf16x3 tune {tune}")
+    ref = P.assert_spline_log_prob(f.log_prob(x), spec, x, f"rqs bf16x3 tune {tune}")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
 
 

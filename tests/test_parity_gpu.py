@@ -20,13 +20,73 @@ pytestmark = pytest.mark.gpu
 DENSITIES = ["banana", "energy1", "energy2", "energy3", "energy4", "gaussian_blobs"]
 
 
-# Spline paths: a sample whose float64 value an all-float32 evaluation cannot reach either (a nearly flat or nearly
-# vertical piece of the spline: the NumPy float32 restatement itself is further than 1e-5 away there) is allowed
-# SPLINE_F32_FACTOR times the float32 restatement's own error ON THAT SAMPLE -- never a batch-wide floor.  Measured
-# (tests/tools/rqs_error_stats.py): the kernels carry the knots in float64 and sit 5-6x closer to
-# float64 than NumPy float32 does (log_prob worst 1.0e-6 ... 6.6e-6 scaled on configs[2]), so the escape only
-# matters for a handful of ill-conditioned samples per 16,384.
-SPLINE_F32_FACTOR = 2.0
+# Spline paths.  Asserted for every spline output (log_prob, z, logdet):
+#   (i)  on the BASELINE configs (configs[2] at test size and at 2^20 rows, the fused kernel's shapes): all but
+#        SPLINE_ESCAPE_FRACTION of the samples are within 1e-5 * max(1, |float64|) -- the tolerance of every test
+#        here, no floor.  (Deliberately hard synthetic cases -- inputs far outside the spline's range, last Linears
+#        three times the scale -- have up to 6 % of their samples beyond 1e-5 in ANY float32 evaluation and assert
+#        (ii) only.)
+#  (ii)  everywhere: a sample is within 1e-5 * max(1, |float64|), or -- on a nearly flat or nearly vertical piece of
+#        a spline, where a float32 CONDITIONER cannot resolve the float64 value -- within SPLINE_F32_FACTOR x
+#        float32's own noise ON THAT SAMPLE, measured as the largest distance from float64 among F32_ENSEMBLE NumPy
+#        float32 evaluations of the SAME flow that differ only in the order of the conditioner's sums (hidden units
+#        permuted: mathematically the identity) and, for every second one, in the last bit of the inputs.
+# Why not "2 x |numpy_f32_i - float64_i|": that bound fails NumPy float32 against ITSELF -- on configs[2] / energy2 a
+# second summation order violates it on 0.35 % of the samples (tests/tools/f32_noise_study.py: the per-sample error is
+# heavy-tailed, a single evaluation is often 1e-6 away by luck where the next order is 3e-5 away), and the kernel's
+# MFMA chain is one more such order.  Measured (tests/tools/rqs_error_stats.py): the kernels carry the
+# knots in float64 and sit 5-6x closer to float64 than NumPy float32 does (log_prob worst 1.0e-6 ... 6.6e-6 scaled on
+# configs[2], 3 of 16,384 logdets outside 1e-5 where NumPy float32 has 310); what is left is the float32 conditioner,
+# i.e. exactly this noise.  (i) is what would catch a regression to NumPy-float32 accuracy (1.9 % outside).
+SPLINE_F32_FACTOR = 8.0
+F32_ENSEMBLE = 8
+SPLINE_ESCAPE_FRACTION = 2e-3
+
+
+def permuted_specs(spec, n=F32_ENSEMBLE):
+    """The flow itself plus n-1 copies with every conditioner's hidden units permuted: same function, other float32
+    summation orders."""
+    out = [spec]
+    for k in range(1, n):
+        rng = np.random.default_rng(9000 + k)
+        layers = []
+        for layer in spec.layers:
+            new, perm_in = [], None
+            for j, (W, b) in enumerate(layer):
+                W, b = np.asarray(W), np.asarray(b)
+                if perm_in is not None:
+                    W = W[perm_in]
+                if j < len(layer) - 1:
+                    perm_in = rng.permutation(W.shape[1])
+                    W, b = W[:, perm_in], b[perm_in]
+                new.append((np.ascontiguousarray(W), np.ascontiguousarray(b)))
+            layers.append(new)
+        c = O.FlowSpec(spec.kind, spec.event_size, layers, spec.masks, spec.base, spec.num_bins, spec.range_min,
+                       spec.range_max, spec.min_bin_size, spec.min_knot_slope)
+        if hasattr(spec, "activation"):
+            c.activation = spec.activation
+        out.append(c)
+    return out
+
+
+def f32_noise(spec, fn, ref, x):
+    """max over the ensemble of |fn(spec_k, x_k) - ref|, elementwise; fn(spec, x) evaluates in float32 and returns an
+    array or a tuple of arrays.  Member 0 is (spec, x) itself; the others permute the hidden units, and every second
+    one also moves each input to a neighbouring float32 (the state of a float32 chain is rounded to float32 after every
+    layer: a value that changes when its input moves by one unit in the last place cannot be resolved by ANY float32
+    evaluation -- e.g. a 1e-4-wide bin at |x| ~ 4, where the knot itself is only known to 2.4e-7)."""
+    noise = None
+    x32 = np.asarray(x, np.float32)
+    for k, c in enumerate(permuted_specs(spec)):
+        xk = x32
+        if k and k % 2 == 0:
+            rng = np.random.default_rng(7000 + k)
+            xk = np.nextafter(x32, np.where(rng.integers(0, 2, x32.shape) == 1, np.float32(np.inf), np.float32(-np.inf)))
+        got = fn(c, xk)
+        got = got if isinstance(got, tuple) else (got,)
+        e = [np.abs(np.asarray(g, np.float64) - r) for g, r in zip(got, ref if isinstance(ref, tuple) else (ref,))]
+        noise = e if noise is None else [np.maximum(a, b) for a, b in zip(noise, e)]
+    return noise if isinstance(ref, tuple) else noise[0]
 
 
 def tol(ref):
@@ -44,34 +104,55 @@ def assert_close(got, ref, what, floor=0.0):
                            f"{np.nanmax(np.abs(got - ref))} at ref {ref.ravel()[np.nanargmax(np.abs(got - ref))]}")
 
 
-def spline_ok(got, ref, ref32):
-    """Per element: within 1e-5 * max(1, |ref|), or within SPLINE_F32_FACTOR x the float32 restatement's own
-    error on the same element."""
-    got, ref, ref32 = (np.asarray(a, np.float64) for a in (got, ref, ref32))
-    assert got.shape == ref.shape == ref32.shape, (got.shape, ref.shape, ref32.shape)
+def spline_ok(got, ref, noise):
+    """Per element: within 1e-5 * max(1, |ref|), or within SPLINE_F32_FACTOR x float32's own noise on the same
+    element (f32_noise)."""
+    got, ref, noise = (np.asarray(a, np.float64) for a in (got, ref, noise))
+    assert got.shape == ref.shape == noise.shape, (got.shape, ref.shape, noise.shape)
     err = np.abs(got - ref)
-    return (err <= np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(ref32 - ref))) | (got == ref)
+    return (err <= np.maximum(tol(ref), SPLINE_F32_FACTOR * noise)) | (got == ref)
 
 
-def assert_spline_close(got, ref, ref32, what):
-    ok = spline_ok(got, ref, ref32)
+def assert_spline_close(got, ref, noise, what, escape_fraction=None):
+    ok = spline_ok(got, ref, noise)
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    if escape_fraction is not None:
+        plain = (np.abs(got - ref) <= tol(ref)) | (got == ref)
+        allowed = max(2, int(escape_fraction * plain.size))
+        assert int((~plain).sum()) <= allowed, (f"{what}: {int((~plain).sum())}/{plain.size} samples outside 1e-5 * max(1, "
+                                                f"|ref|) (at most {allowed} may use the float32-noise escape), worst "
+                                                f"scaled {np.nanmax(err):.3e}")
     assert ok.all(), (f"{what}: {int((~ok).sum())}/{ok.size} outside max(1e-5 scaled, {SPLINE_F32_FACTOR} x float32's own "
-                      f"error), worst scaled {np.nanmax(np.where(ok, 0, err)):.3e} at ref "
+                      f"noise), worst scaled {np.nanmax(np.where(ok, 0, err)):.3e} at ref "
                       f"{ref.ravel()[np.nanargmax(np.where(ok, 0, err))]}")
 
 
-def assert_spline_forward(f, spec, x, what):
+def assert_spline_log_prob(got, spec, x, what, escape_fraction=None):
+    """log_prob values `got` of flow `spec` on rows x against float64, per-sample bound.  Returns the reference."""
+    ref = O.log_prob(spec, x)
+    assert_spline_close(got, ref, f32_noise(spec, lambda c, v: O.log_prob(c, v, np.float32), ref, x), what, escape_fraction)
+    return ref
+
+
+def sample_noise(spec, z):
+    """float32 noise of the generative walk from base draws z (elementwise)."""
+    ref = O.sample_from_z(spec, z)
+    with np.errstate(all="ignore"):
+        return f32_noise(spec, lambda c, v: O.sample_from_z(c, v, np.float32), ref, z)
+
+
+def assert_spline_forward(f, spec, x, what, escape_fraction=None):
     """log_prob, z and logdet of the density-evaluation walk against float64, per-sample bound."""
     from normalizing_flows_amd import _lib
     ref = O.log_prob(spec, x)
-    assert_spline_close(f.log_prob(x), ref, O.log_prob(spec, x, np.float32), f"{what} log_prob")
+    assert_spline_close(f.log_prob(x), ref, f32_noise(spec, lambda c, v: O.log_prob(c, v, np.float32), ref, x), f"{what} log_prob",
+                        escape_fraction)
     z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
     zr, ldr = O.chain_forward(spec, x)
-    z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_spline_close(z, zr, z32, f"{what} z")
-    assert_spline_close(ld, ldr, ld32, f"{what} logdet")
+    nz, nld = f32_noise(spec, lambda c, v: O.chain_forward(c, v, np.float32), (zr, ldr), x)
+    assert_spline_close(z, zr, nz, f"{what} z", escape_fraction)
+    assert_spline_close(ld, ldr, nld, f"{what} logdet", escape_fraction)
     return ref, z
 
 
@@ -83,8 +164,9 @@ def assert_spline_inverse(f, spec, z, what):
     from normalizing_flows_amd import _lib
     xb, ldb = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
     xr, ldr = O.chain_inverse(spec, z)
-    x32, ld32 = O.chain_inverse(spec, z, np.float32)
-    fwd_ok = spline_ok(xb, xr, x32).all(axis=-1) & spline_ok(ldb, ldr, ld32)
+    with np.errstate(all="ignore"):
+        nx, nld = f32_noise(spec, lambda c, v: O.chain_inverse(c, v, np.float32), (xr, ldr), z)
+    fwd_ok = spline_ok(xb, xr, nx).all(axis=-1) & spline_ok(ldb, ldr, nld)
     zb, ldf = O.chain_forward(spec, xb)
     zz = np.asarray(z, np.float64)
     bwd_ok = (np.abs(zb - zz) <= tol(zz)).all(axis=-1) & (np.abs(np.asarray(ldb, np.float64) + ldf) <= tol(ldf))
@@ -464,7 +546,7 @@ def test_rqs_toy_config3(nfa, density):
     spec = O.make_rqs_spec(8, final_std=0.05)
     f = rqs_flow(nfa, spec)
     x = O.make_inputs(density, 4096)
-    ref, z = assert_spline_forward(f, spec, x, f"rqs {density}")
+    ref, z = assert_spline_forward(f, spec, x, f"rqs {density}", SPLINE_ESCAPE_FRACTION)
     assert_spline_inverse(f, spec, z, f"rqs {density} inverse")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
 
@@ -606,15 +688,15 @@ def test_rqs_fused_kernel_shapes(nfa, K, L, parity, rows, lo, hi):
     f = rqs_flow(nfa, spec, parity)
     assert f.kernel_name == "rqs2d_h64_mfma"
     x = O.make_inputs("banana", rows, seed=K * 100 + L)   # banana leaves [-8, 8]: tails are exercised
-    ref, z = assert_spline_forward(f, spec, x, "fused rqs")
+    ref, z = assert_spline_forward(f, spec, x, "fused rqs", SPLINE_ESCAPE_FRACTION)
     assert_spline_inverse(f, spec, z, "fused rqs inverse")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
     for l in range(min(L, 3)):
         y, d = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x, l, l + 1)
         yr, dr = O.coupling_layer(spec, l, x, False)
-        y32, d32 = O.coupling_layer(spec, l, x, False, np.float32)
-        assert_spline_close(y, yr, y32, f"fused rqs layer {l}")
-        assert_spline_close(d, dr, d32, f"fused rqs layer {l} logdet")
+        ny, nd = f32_noise(spec, lambda c, v: O.coupling_layer(c, l, v, False, np.float32), (yr, dr), x)
+        assert_spline_close(y, yr, ny, f"fused rqs layer {l}")
+        assert_spline_close(d, dr, nd, f"fused rqs layer {l} logdet")
 
 
 def test_rqs_fused_identity_and_edges(nfa):
@@ -627,7 +709,8 @@ def test_rqs_fused_identity_and_edges(nfa):
     assert np.abs(y - x).max() <= 1e-5 and np.abs(ld).max() <= 1e-5
     spec2 = O.make_rqs_spec(3, final_std=0.5, num_bins=8, range_min=-2.0, range_max=2.0, first_parity=0)
     f2 = rqs_flow(nfa, spec2, 0)
-    assert_spline_close(f2.log_prob(x), O.log_prob(spec2, x), O.log_prob(spec2, x, np.float32), "fused rqs edge inputs")
+    ref2 = O.log_prob(spec2, x)
+    assert_spline_close(f2.log_prob(x), ref2, f32_noise(spec2, lambda c, v: O.log_prob(c, v, np.float32), ref2, x), "fused rqs edge inputs")
 
 
 @pytest.mark.parametrize("K,D,hidden,L,rows", [(12, 2, (64, 64), 8, 4096), (8, 2, (64, 64), 3, 1000),
@@ -676,9 +759,9 @@ def test_rqs_spline_in_gemm_epilogue(nfa, monkeypatch, mode, K, D, hidden, L, ro
     g.set_option("hidden_matmul", mode)
     plain = g.log_prob(x)
     # the unfused form of the same arithmetic: both within the bound of float64, hence within twice it of each other
-    lp32 = O.log_prob(spec, x, np.float32)
-    assert_spline_close(plain, ref, lp32, "unfused log_prob")
-    assert (np.abs(plain.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(lp32 - ref))).all()
+    noise = f32_noise(spec, lambda c, v: O.log_prob(c, v, np.float32), ref, x)
+    assert_spline_close(plain, ref, noise, "unfused log_prob")
+    assert (np.abs(plain.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * noise)).all()
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
@@ -730,15 +813,15 @@ def test_general_path_small_batches_split_k(nfa, monkeypatch, kind, D, hidden, r
         make = lambda: rqs_flow(nfa, spec)
     x = (np.random.default_rng(D + rows).standard_normal((rows, D)) * 1.5).astype(np.float32)
     ref = O.log_prob(spec, x)
-    lp32 = O.log_prob(spec, x, np.float32)
+    noise = f32_noise(spec, lambda c, v: O.log_prob(c, v, np.float32), ref, x)
     f = make()
     assert f.kernel_name == "generic_gemm"
     got = f.log_prob(x)
-    assert_spline_close(got, ref, lp32, "split-K log_prob")
+    assert_spline_close(got, ref, noise, "split-K log_prob")
     monkeypatch.setenv("NF_NO_SPLITK", "1")
     whole = make().log_prob(x)
-    assert_spline_close(whole, ref, lp32, "whole-K log_prob")
-    assert (np.abs(whole.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * np.abs(lp32 - ref))).all()
+    assert_spline_close(whole, ref, noise, "whole-K log_prob")
+    assert (np.abs(whole.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * noise)).all()
 
 
 # ------------------------------------------------------------------ backward pass / training step

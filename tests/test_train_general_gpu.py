@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 from oracle import flows_np as O
-from test_parity_gpu import _flat, affine_flow, assert_close, rqs_flow
+from test_parity_gpu import (_flat, affine_flow, assert_close, assert_spline_forward, assert_spline_inverse,
+                             assert_spline_log_prob, rqs_flow)
 
 pytestmark = pytest.mark.gpu
 
@@ -123,13 +124,12 @@ def test_spline_adam_steps_and_fused_kernel_follows(nfa):
     new_spec.layers = f.get_weights()
     x = O.make_inputs("gaussian_blobs", 3000, seed=7)
     ref = O.log_prob(new_spec, x)
-    e32 = np.abs(O.log_prob(new_spec, x, np.float32) - ref).max()
     assert f.kernel_name == "rqs2d_h64_mfma"
-    assert_close(f.log_prob(x), ref, "fused spline log_prob after training", 4 * e32)
+    assert_spline_log_prob(f.log_prob(x), new_spec, x, "fused spline log_prob after training")
     assert abs(f.nll(x) + ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean()))
     # new weights from the host restart the optimiser state and reach both representations
     f.set_weights(spec.layers)
-    assert_close(f.log_prob(x), O.log_prob(spec, x), "after set_weights", 4 * e32)
+    assert_spline_log_prob(f.log_prob(x), spec, x, "after set_weights")
     check_grads(f, spec, x)
 
 
@@ -232,18 +232,8 @@ def test_random_shapes_forward_and_gradient(nfa, case):
         f = affine_flow(nfa, spec, parity)
     assert f.kernel_name == "generic_gemm"
     x = (rng.standard_normal((rows, D)) * 2.0).astype(np.float32)
-    ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, f"case {case} log_prob", 4 * e32)
-    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
-    zr, ldr = O.chain_forward(spec, x)
-    z32, ld32 = O.chain_forward(spec, x, np.float32)
-    assert_close(z, zr, f"case {case} z", 4 * np.abs(z32 - zr).max())
-    assert_close(ld, ldr, f"case {case} logdet", 4 * np.abs(ld32 - ldr).max())
-    xb, _ = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
-    xr, _ = O.chain_inverse(spec, z)
-    x32, _ = O.chain_inverse(spec, z, np.float32)
-    assert_close(xb, xr, f"case {case} inverse", 4 * np.abs(x32 - xr).max())
+    _, z = assert_spline_forward(f, spec, x, f"case {case}")
+    assert_spline_inverse(f, spec, z, f"case {case} inverse")
     check_grads(f, spec, x, tol=3e-4)
 
 
@@ -274,8 +264,7 @@ def test_leaky_relu_conditioner_forward_and_gradient(nfa, kind):
     f = nfa.CouplingFlow(cfg, spec.layers)
     x = (rng.standard_normal((900, spec.event_size)) * 1.5).astype(np.float32)
     ref = O.log_prob(spec, x)
-    e32 = np.abs(O.log_prob(spec, x, np.float32) - ref).max()
-    assert_close(f.log_prob(x), ref, "leaky_relu log_prob", 4 * e32)
+    assert_spline_log_prob(f.log_prob(x), spec, x, "leaky_relu log_prob")
     relu_spec_lp = O.log_prob(type(spec)(spec.kind, spec.event_size, spec.layers, spec.masks, spec.base,
                                          spec.num_bins, spec.range_min, spec.range_max), x)
     assert np.abs(relu_spec_lp - ref).max() > 1e-3      # the activation matters on this data
@@ -346,8 +335,10 @@ def test_padded_narrow_flow_trains_in_the_callers_layout(nfa, kind):
     new_spec = fresh()
     new_spec.layers = f.get_weights()
     ref = O.log_prob(new_spec, x)
-    e32 = np.abs(O.log_prob(new_spec, x, np.float32) - ref).max() if kind == "rqs" else 0.0
-    assert_close(f.log_prob(x), ref, "padded flow after training", 4 * e32)
+    if kind == "rqs":
+        assert_spline_log_prob(f.log_prob(x), new_spec, x, "padded flow after training")
+    else:
+        assert_close(f.log_prob(x), ref, "padded flow after training")
     g_before = f.nll_grad(x)[1]
     w_before = _flat(f.get_weights())
     f.train_step(x, training.sgd(0.01))
@@ -381,6 +372,13 @@ def test_skip_nonfinite_updates(nfa, kind):
     loss = f.train_step(good, opt)
     w1 = _flat(f.get_weights())
     assert np.isfinite(loss) and np.isfinite(w1).all() and np.abs(w1 - w0).max() > 1e-4
+    # the skipped step does not count: Adam's bias correction on the applied step is that of step 1, so the
+    # weights equal those of a fresh handle after its first step on the same batch (optax.apply_if_finite keeps
+    # the inner optimiser's count where it was); with the count advanced the update would be 0.53x / 0.71x as large
+    h = make()
+    h.set_option("skip_nonfinite_updates", "1")
+    h.train_step(good, opt)
+    assert np.abs(_flat(h.get_weights()) - w1).max() <= 1e-7 * max(1.0, np.abs(w1).max())
     g = make()
     g.train_step(bad, opt)
     assert not np.isfinite(_flat(g.get_weights())).all()

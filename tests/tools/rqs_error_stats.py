@@ -78,9 +78,19 @@ def main():
                 key = (name, what)
                 worst[key] = max(worst.get(key, 0.0), float(e.max()))
             # per-sample bound the tests use: max(1e-5 * scale, 2 * |f32_i - f64_i|)
-            e = np.abs(lp.astype(np.float64) - ref)
-            bound = np.maximum(1e-5 * np.maximum(1.0, np.abs(ref)), 2 * np.abs(lp32.astype(np.float64) - ref))
-            print(f"   log_prob outside the per-sample bound: {int((e > bound).sum())}")
+            def outside(got, r64, r32):
+                e = np.abs(np.asarray(got, np.float64) - r64)
+                bound = np.maximum(1e-5 * np.maximum(1.0, np.abs(r64)), 2 * np.abs(np.asarray(r32, np.float64) - r64))
+                return int((e > bound).sum())
+            x32, ldi32 = O.chain_inverse(spec, zf, np.float32)
+            zb, ldf = O.chain_forward(spec, xb)
+            bwd = (np.abs(zb - zf) <= 1e-5 * np.maximum(1, np.abs(zf))).all(-1) & \
+                  (np.abs(ldb + ldf) <= 1e-5 * np.maximum(1, np.abs(ldf)))
+            fwd = (np.abs(xb - xr) <= np.maximum(1e-5 * np.maximum(1, np.abs(xr)), 2 * np.abs(x32 - xr))).all(-1) & \
+                  (np.abs(ldb - ldir) <= np.maximum(1e-5 * np.maximum(1, np.abs(ldir)), 2 * np.abs(ldi32 - ldir)))
+            print(f"   outside the per-sample bound: log_prob {outside(lp, ref, lp32)}, z {outside(z, zr, z32)}, "
+                  f"logdet {outside(ld, ldr, ld32)}; inverse rows failing forward AND backward bound: "
+                  f"{int((~(fwd | bwd)).sum())} (forward alone {int((~fwd).sum())})")
     print("worst over the three densities:")
     for (name, what), v in worst.items():
         print(f"   {name:24s} {what:16s} {v:.2e}")
