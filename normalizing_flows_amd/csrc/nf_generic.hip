@@ -204,6 +204,128 @@ __device__ __forceinline__ void gemm_fast_mainloop(const float* __restrict__ A, 
   }
 }
 
+// The same k loop for the case every large GEMM of the path is in (K a multiple of 32, N a multiple of 128; rows
+// may be ragged): what differs is everything BUT the MFMAs.  gemm_fast_mainloop spends ~90 VALU instructions per k
+// tile and wave beside its 64 MFMAs -- predicates, zero-fills and 64-bit address arithmetic of eight guarded loads,
+// address adds for 64 scalar LDS operand reads -- and on gfx950 every one of them costs the MFMA pipe its cycles
+// (DESIGN.md section 4).  Here
+//   * loads are unconditional buffer loads (one descriptor per operand built from uniform values, the thread's share
+//     as a 32-bit byte offset, the k tile's advance as the scalar offset): K and N need no guard, rows past M are
+//     clamped to M - 1 (their products are computed and never stored) -- no branches, no zero-fills, no 64-bit
+//     vector addresses (eight of those did not fit beside 64 accumulator + 32 prefetch registers at four workgroups
+//     per CU: they were spilled and reloaded every k tile);
+//   * the LDS tiles hold each lane's OPERAND PAIRS side by side -- A as [wm][k][i][{row i, row i + 32}], W as
+//     [k][wn][i][{col i, col i + 32}] -- so a k step is two aligned 8-byte reads with immediate offsets instead of
+//     four ds_read_b32 behind computed addresses;
+//   * stores are laid out for the LDS's store banking (32 banks, 16-lane groups for 8-byte stores): A rows are
+//     padded to 66 floats and the rows of k >= 16 are rotated by two lanes, so that the eight lanes that hold one
+//     A row's 32 k values hit distinct banks; a thread loads W as two float2 (columns c, c+1 and c+32, c+33) and
+//     stores them as ONE 16-byte write of two whole pairs.  (A first version kept float4 W loads and scattered
+//     them with 4-byte stores: 4-way bank conflicts, SQ_LDS_BANK_CONFLICT 338 M cycles per launch, 18 % slower
+//     than the loop it replaced.)
+// Same sums in the same order as gemm_fast_mainloop: results are bit-identical.
+constexpr int kFullARow = 66;  // floats per k row of one wm half: 32 lanes x 2 + 2 pad
+static_assert(2 * FBK * kFullARow + FBK * FBN <= kFastLdsFloats, "full-tile layout must fit the shared LDS stage");
+
+__device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                   int M, int N, int K, int m0, int n0, float* smem,
+                                                   f32x16 (&acc)[2][2]) {
+  constexpr int kAs = 2 * FBK * kFullARow;  // A tile, then the W tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // this thread's share of a k tile.  A: rows ar + 32 e (e < 4), k quad akq.  W: rows wk + 8 e, the column pairs
+  // (wc, wc + 1) and (wc + 32, wc + 33) of half wh
+  const int ar = tid >> 3, akq = (tid & 7) * 4;
+  const int wk = tid >> 5, wh = (tid >> 4) & 1, wc = wh * 64 + 2 * (tid & 15);
+  const __amdgpu_buffer_rsrc_t arsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + n0), 0, 0x7fffffff, 0x00020000);
+  unsigned aoff[4], woff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    aoff[e] = ((unsigned)(min(m0 + ar + 32 * e, M - 1) - m0) * (unsigned)lda + akq) * 4u;
+    woff[e] = ((unsigned)(wk + 8 * e) * (unsigned)N + wc) * 4u;
+  }
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[4];
+  unsigned rw[4][4];  // per W row: columns wc, wc + 32, wc + 1, wc + 33 -- the order of the 16-byte LDS store
+  auto fetch = [&](int kt) {
+    const int asoff = kt * (FBK * 4), wsoff = kt * (FBK * 4) * N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ra[e] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[e], asoff, 0);
+      // four dword loads instead of two 8-byte ones: each value lands in the register the store needs it in (packing
+      // two float2 into pair order cost four v_mov per row -- on this part VALU instructions are paid in MFMA time,
+      // loads are not)
+      rw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e], wsoff, 0);
+      rw[e][1] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 128u, wsoff, 0);
+      rw[e][2] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 4u, wsoff, 0);
+      rw[e][3] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 132u, wsoff, 0);
+    }
+  };
+  // A: rows ar + 32 e = wm' * 64 + j * 32 + ar with e = 2 wm' + j: the thread holds both j of a pair; its four k
+  // are akq .. akq + 3, all on one side of 16: lane rotation (akq >> 4) * 2.  A pair's halves sit in the k-th register
+  // of two different 16-byte loads; ds_write2_b32 takes its two dwords from two unrelated registers (the compiler
+  // would instead fuse the stores into 8-byte ones and insert a v_mov per half: 16 per k tile).
+  const unsigned sa0 = (unsigned)(size_t)(smem + akq * kFullARow + 2 * ((ar + 2 * (akq >> 4)) & 31));  // LDS byte address
+  const unsigned sa1 = sa0 + FBK * kFullARow * 4;
+  float* sw = smem + kAs + wk * FBN + wh * 64 + 4 * (tid & 15);
+#define NF_A_PAIR(base_, q_, lo_, hi_)                                                                                 \
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base_), "v"(lo_), "v"(hi_), "n"((q_)*kFullARow), \
+               "n"((q_)*kFullARow + 1)                                                                                 \
+               : "memory")
+  auto stash = [&]() {
+    NF_A_PAIR(sa0, 0, ra[0][0], ra[1][0]); NF_A_PAIR(sa0, 1, ra[0][1], ra[1][1]);
+    NF_A_PAIR(sa0, 2, ra[0][2], ra[1][2]); NF_A_PAIR(sa0, 3, ra[0][3], ra[1][3]);
+    NF_A_PAIR(sa1, 0, ra[2][0], ra[3][0]); NF_A_PAIR(sa1, 1, ra[2][1], ra[3][1]);
+    NF_A_PAIR(sa1, 2, ra[2][2], ra[3][2]); NF_A_PAIR(sa1, 3, ra[2][3], ra[3][3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<float4*>(sw + 8 * e * FBN) = make_float4(__uint_as_float(rw[e][0]), __uint_as_float(rw[e][1]),
+                                                                  __uint_as_float(rw[e][2]), __uint_as_float(rw[e][3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores above are invisible to the compiler's counters
+  };
+#undef NF_A_PAIR_UNUSED
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = K / FBK;
+  fetch(0);
+  stash();
+  __syncthreads();
+  // operand reads: k = 2 s + h; rows / columns i and i + 32 of this wave's half.  Two A bases: k < 16 and k >= 16
+  const float2* as_lo = reinterpret_cast<const float2*>(smem + (wm * FBK + h) * kFullARow) + i;
+  const float2* as_hi = reinterpret_cast<const float2*>(smem + (wm * FBK + h) * kFullARow) + ((i + 2) & 31);
+  const float2* ws = reinterpret_cast<const float2*>(smem + kAs + h * FBN) + wn * 32 + i;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+    for (int s = 0; s < FBK / 2; ++s) {
+      const float2 a = (s < 8 ? as_lo : as_hi)[s * kFullARow];
+      const float2 b = ws[s * FBN];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with this tile
+    if (kt + 1 < nk) {
+      stash();
+      __syncthreads();
+    }
+  }
+}
+
+// K, N as gemm_full_mainloop needs them?  (alignment of the bases and of lda is the fast path's own condition)
+static inline bool gemm_full_ok(int N, int K) { return (K % FBK) == 0 && (N % FBN) == 0 && getenv("NF_GEMM_NO_FULL") == nullptr; }
+
+template <bool FULL>
 __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Cm, int ldc, int M, int N, int K, int act, int gx, int gy, const float* __restrict__ aux) {
@@ -216,8 +338,41 @@ __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
   block_to_tile(blockIdx.x, gx, gy, mb, nb);
   const int m0 = mb * FBM, n0 = nb * FBN;
   f32x16 acc[2][2];
-  gemm_fast_mainloop(A, lda, W, M, N, K, m0, n0, smem, acc);
+  if (FULL) gemm_full_mainloop(A, lda, W, M, N, K, m0, n0, smem, acc);
+  else gemm_fast_mainloop(A, lda, W, M, N, K, m0, n0, smem, acc);
 
+  if (FULL) {
+    // Epilogue without per-element predicates or 64-bit addresses (the guarded form below costs ~30 VALU
+    // instructions per output: 1,900 per wave and tile against 1,024 MFMAs).  One buffer descriptor over the rows
+    // [m0, M) of C: rows past M fall outside it and the hardware drops their stores; columns need no guard
+    // (N is a multiple of 128).  The lane's part of the address is one 32-bit offset, the (t, u, r) part is uniform.
+    const long long left = (long long)(M - m0) * ldc * 4;
+    const unsigned bytes = left > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left;
+    const __amdgpu_buffer_rsrc_t crsrc =
+        __builtin_amdgcn_make_buffer_rsrc(Cm + (size_t)m0 * ldc, 0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(act >= 3 ? aux + (size_t)m0 * ldc : Cm + (size_t)m0 * ldc), 0, (int)bytes, 0x00020000);
+    const unsigned voff = ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + (unsigned)(n0 + wn * 64 + i)) * 4u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float bv = bias[n0 + wn * 64 + u * 32 + i];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int soff = ((t * 32 + 8 * (r >> 2) + (r & 3)) * ldc + u * 32) * 4;
+          float v = acc[t][u][r] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 2) v = fmaxf(v, 0.01f * v);
+          else if (act >= 3) {
+            const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, soff, 0));
+            v = a > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crsrc, voff, soff, 0);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -320,7 +475,9 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
   if (aligned && N >= 128 && K >= 32 && getenv("NF_GEMM_SIMPLE") == nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
-      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel),
+      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       attr_set = true;
     }
@@ -347,8 +504,12 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
       NF_HIP(hipGetLastError());
       return NF_OK;
     }
-    hipLaunchKernelGGL(gemm_fast_kernel, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
-                       W, bias, Cm, ldc, M, N, K, act, gx, gy, aux);
+    if (gemm_full_ok(N, K))
+      hipLaunchKernelGGL(gemm_fast_kernel<true>, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
+                         W, bias, Cm, ldc, M, N, K, act, gx, gy, aux);
+    else
+      hipLaunchKernelGGL(gemm_fast_kernel<false>, dim3(gx * gy), dim3(256), kFastLdsFloats * sizeof(float), stream, A,
+                         lda, W, bias, Cm, ldc, M, N, K, act, gx, gy, aux);
     NF_HIP(hipGetLastError());
     return NF_OK;
   }
@@ -566,7 +727,7 @@ static bool launch_rqs_rows(float* y, float* ld, const float* params, long long 
 // ------------------------------------------------------------------------
 constexpr int kRqsLdsFloats = (kFastLdsFloats > 64 * kCtStride ? kFastLdsFloats : 64 * kCtStride) + 64 * 8;
 
-template <int K, int INV>
+template <int K, int INV, bool FULL>
 __global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           float* __restrict__ y, float* __restrict__ ldpart, int M,
@@ -577,7 +738,8 @@ __global__ __launch_bounds__(256, 4) void gemm_rqs_kernel(const float* __restric
   block_to_tile(blockIdx.x, gx, gy, mb, nb);
   const int m0 = mb * FBM, n0 = nb * FBN;
   f32x16 acc[2][2];
-  gemm_fast_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);
+  if (FULL) gemm_full_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);
+  else gemm_fast_mainloop(A, lda, W, M, Npad, Kdim, m0, n0, smem, acc);
 
   rqs_tile_epilogue<K, INV>(acc, bias, n0, m0, nb, M, D, pass_parity, y, ldpart, smem, smem + kRqsLdsFloats - 64 * 8, c);
 }
@@ -618,22 +780,22 @@ template <int K>
 static int launch_gemm_rqs(const float* A, int lda, const float* Wk5, const float* bk5, float* y, float* ldpart,
                            float* ld, int M, int Npad, int Kdim, int D, int par, int inverse, const RqsConst& rc,
                            hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rqs_kernel<K, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rqs_kernel<K, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
-  }
   const int gx = Npad / FBN, gy = (M + FBM - 1) / FBM;
   const size_t lds = kRqsLdsFloats * sizeof(float);
-  if (inverse)
-    hipLaunchKernelGGL((gemm_rqs_kernel<K, 1>), dim3(gx * gy), dim3(256), lds, stream, A, lda, Wk5, bk5, y, ldpart, M,
-                       Npad, Kdim, D, par, gx, gy, rc);
-  else
-    hipLaunchKernelGGL((gemm_rqs_kernel<K, 0>), dim3(gx * gy), dim3(256), lds, stream, A, lda, Wk5, bk5, y, ldpart, M,
-                       Npad, Kdim, D, par, gx, gy, rc);
+  typedef void (*Kernel)(const float*, int, const float*, const float*, float*, float*, int, int, int, int, int, int, int,
+                         RqsConst);
+  static const Kernel kernels[2][2] = {{&gemm_rqs_kernel<K, 0, false>, &gemm_rqs_kernel<K, 0, true>},
+                                       {&gemm_rqs_kernel<K, 1, false>, &gemm_rqs_kernel<K, 1, true>}};
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b]),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernels[inverse ? 1 : 0][gemm_full_ok(Npad, Kdim) ? 1 : 0], dim3(gx * gy), dim3(256), lds, stream, A,
+                     lda, Wk5, bk5, y, ldpart, M, Npad, Kdim, D, par, gx, gy, rc);
   return launch_ld_reduce(ldpart, gx, M, ld, stream);
 }
 
