@@ -266,7 +266,10 @@ struct Plan {
 // (Row-major order streamed the whole 20-30 MB weight image of the MNIST-shape last Linear through every
 // XCD for every row block: 11-17 GB of fabric reads per launch against 0.5 GB algorithmic, rocprofv3
 // FETCH_SIZE)
-constexpr int kTileBand = 8;
+#ifndef NF_TILE_BAND
+#define NF_TILE_BAND 8
+#endif
+constexpr int kTileBand = NF_TILE_BAND;
 __device__ __forceinline__ void block_to_tile(int id, int gx, int gy, int& mb, int& nb) {
   const int nblk = gx * gy;
   const int base = nblk >> 3, rem = nblk & 7, x = id & 7;
