@@ -204,8 +204,8 @@ __device__ __forceinline__ void gemm_fast_mainloop(const float* __restrict__ A, 
   }
 }
 
-// The same k loop for the case every large GEMM of the path is in (K a multiple of 32, N a multiple of 128; rows
-// may be ragged): what differs is everything BUT the MFMAs.  gemm_fast_mainloop spends ~90 VALU instructions per k
+// The same k loop for the case every large GEMM of the path is in (N a multiple of 128; rows may be ragged, and so may
+// the last k tile: K a multiple of 4): what differs is everything BUT the MFMAs.  gemm_fast_mainloop spends ~90 VALU instructions per k
 // tile and wave beside its 64 MFMAs -- predicates, zero-fills and 64-bit address arithmetic of eight guarded loads,
 // address adds for 64 scalar LDS operand reads -- and on gfx950 every one of them costs the MFMA pipe its cycles
 // (DESIGN.md section 4).  Here
@@ -239,9 +239,15 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
   // (wc, wc + 1) and (wc + 32, wc + 33) of half wh
   const int ar = tid >> 3, akq = (tid & 7) * 4;
   const int wk = tid >> 5, wh = (tid >> 4) & 1, wc = wh * 64 + 2 * (tid & 15);
-  const __amdgpu_buffer_rsrc_t arsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m0 * lda), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + n0), 0, 0x7fffffff, 0x00020000);
+  // A's descriptor ends with the last row's K-th float: the ragged k tile's overrun of the LAST row reads zeros
+  // instead of leaving the allocation (other rows' overrun lands in the next row and is cleared in stash)
+  const long long aleft = ((long long)(M - m0 - 1) * lda + K) * 4;
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A + (size_t)m0 * lda), 0, aleft > 0x7fffffffLL ? 0x7fffffff : (int)aleft, 0x00020000);
+  // W's descriptor ends with the matrix: in a ragged last k tile the rows past K read as zeros (range check)
+  const long long wleft = ((long long)K * N - n0) * 4;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(W + n0), 0, wleft > 0x7fffffffLL ? 0x7fffffff : (int)wleft, 0x00020000);
   unsigned aoff[4], woff[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -276,7 +282,14 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
   asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base_), "v"(lo_), "v"(hi_), "n"((q_)*kFullARow), \
                "n"((q_)*kFullARow + 1)                                                                                 \
                : "memory")
-  auto stash = [&]() {
+  const int ktail = K % FBK;  // a multiple of 4 (the fast path's alignment condition)
+  auto stash = [&](bool tail) {
+    if (tail && akq >= ktail) {
+      // last, partial k tile: this thread's k quad lies past K -- its loads fetched the next row's leading floats.
+      // W reads zeros there, but 0 * NaN of ANOTHER row must not reach this row's sums: clear them.
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ra[e] = u32x4{0u, 0u, 0u, 0u};
+    }
     NF_A_PAIR(sa0, 0, ra[0][0], ra[1][0]); NF_A_PAIR(sa0, 1, ra[0][1], ra[1][1]);
     NF_A_PAIR(sa0, 2, ra[0][2], ra[1][2]); NF_A_PAIR(sa0, 3, ra[0][3], ra[1][3]);
     NF_A_PAIR(sa1, 0, ra[2][0], ra[3][0]); NF_A_PAIR(sa1, 1, ra[2][1], ra[3][1]);
@@ -295,9 +308,9 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = K / FBK;
+  const int nk = (K + FBK - 1) / FBK;
   fetch(0);
-  stash();
+  stash(nk == 1 && ktail != 0);
   __syncthreads();
   // operand reads: k = 2 s + h; rows / columns i and i + 32 of this wave's half.  Two A bases: k < 16 and k >= 16
   const float2* as_lo = reinterpret_cast<const float2*>(smem + (wm * FBK + h) * kFullARow) + i;
@@ -316,14 +329,14 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
     }
     __syncthreads();  // every wave is done with this tile
     if (kt + 1 < nk) {
-      stash();
+      stash(kt + 2 == nk && ktail != 0);
       __syncthreads();
     }
   }
 }
 
 // K, N as gemm_full_mainloop needs them?  (alignment of the bases and of lda is the fast path's own condition)
-static inline bool gemm_full_ok(int N, int K) { return (K % FBK) == 0 && (N % FBN) == 0 && getenv("NF_GEMM_NO_FULL") == nullptr; }
+static inline bool gemm_full_ok(int N, int K) { return K >= FBK && (K % 4) == 0 && (N % FBN) == 0 && getenv("NF_GEMM_NO_FULL") == nullptr; }
 
 template <bool FULL>
 __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(

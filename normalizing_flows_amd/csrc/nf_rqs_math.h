@@ -37,18 +37,17 @@ __device__ __forceinline__ float rcp_nr(float b) {
 }
 __device__ __forceinline__ float fast_div(float a, float b) { return a * rcp_nr(b); }
 
-// log(1 + exp(a)) for a <= 0 with a RELATIVE error of a few 1e-7 down to exp(a) -> 0.  The plain form
-// log(1.f + e) loses e's digits in the sum (absolute error 6e-8: a slope of softplus + min_knot_slope = 1e-4 + 5e-5
-// comes out 4e-4 off, and so does its log in the log-det -- seen on out-of-range inputs of deep chains, where the
-// conditioner sees |x| ~ 30 and emits slope logits of -10).  Below e = 2^-6 the series e - e^2/2 + e^3/3 - e^4/4
-// (truncation e^4/5 relative); above it the hardware log of u = fl(1 + e) plus the first-order term for the part
-// of e that u dropped.
+// log(1 + exp(a)) for a <= 0 with a RELATIVE error of ~2e-7 down to exp(a) -> 0.  The plain form log(1.f + e)
+// loses e's digits in the sum (absolute error 6e-8: a slope of softplus + min_knot_slope = 1e-4 + 5e-5 comes out
+// 4e-4 off, and so does its log in the log-det -- seen on out-of-range inputs of deep chains, where the conditioner
+// sees |x| ~ 30 and emits slope logits of -10).  u = fl(1 + e) drops the low bits of e: they come back as the
+// first-order term (e - (u - 1)) / u ~ (e - (u - 1)) (1 - e); log(u) itself is the hardware's, which is accurate
+// RELATIVE to its result right down to u - 1 = 2^-24 (profiles/microbench/hw_log_near_one.hip: worst 1.1e-7 in every
+// binade, so no series is needed for small e; for u == 1 the correction term alone is e).
 __device__ __forceinline__ float log1p_exp(float a) {
   const float e = __builtin_amdgcn_exp2f(a * 1.44269504f);
   const float u = 1.f + e;
-  const float big = fmaf(e - (u - 1.f), 1.f - e, __builtin_amdgcn_logf(u) * 0.693147181f);
-  const float small = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.333333343f), -0.5f), 1.f);
-  return e < 0.015625f ? small : big;
+  return fmaf(e - (u - 1.f), 1.f - e, __builtin_amdgcn_logf(u) * 0.693147181f);
 }
 
 // softplus(v) = max(v, 0) + log(1 + exp(-|v|))

@@ -488,7 +488,10 @@ def rqs_flow(nfa, spec, parity=1, pad=False):
 
 @pytest.mark.parametrize("D,hidden,L,parity", [(2, (32, 32), 4, 1), (2, (64,), 3, 0), (2, (50, 70), 5, 1),
                                                (2, (64, 64, 64), 2, 1), (4, (64, 64), 4, 1), (5, (33,), 3, 0),
-                                               (7, (16, 16), 2, 1)])
+                                               (7, (16, 16), 2, 1),
+                                               # the full-tile GEMM loop (N % 128 == 0): K = 36 and 44 end in a ragged
+                                               # k tile (4 / 12 of 32), K = 128 / 256 do not; 3001 rows are ragged too
+                                               (36, (128, 256), 2, 1), (44, (256,), 2, 0)])
 def test_generic_affine_masked(nfa, D, hidden, L, parity):
     spec = O.make_affine_spec(L, event_size=D, hidden=hidden, final_std=0.03, first_parity=parity)
     f = affine_flow(nfa, spec, parity)
@@ -929,7 +932,8 @@ def test_split_nll_gradient_and_sgd(nfa, L, H, rows):
 
 # ------------------------------------------------------------------ non-finite and extreme inputs
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-@pytest.mark.parametrize("kind", ["affine_fused", "rqs_fused", "affine_general", "rqs_general", "rqs_general_k4", "split"])
+@pytest.mark.parametrize("kind", ["affine_fused", "rqs_fused", "affine_general", "affine_general_ragged_k", "rqs_general",
+                                  "rqs_general_k4", "split"])
 def test_non_finite_inputs_stay_in_their_rows(nfa, kind, mode):
     """jax propagates NaN through log_prob; a NaN / inf / 1e30 coordinate must make its own row's
     result non-finite (or a huge negative log_prob) and leave every other row exactly as it was --
@@ -945,6 +949,11 @@ def test_non_finite_inputs_stay_in_their_rows(nfa, kind, mode):
     elif kind == "affine_general":
         spec = O.make_affine_spec(2, event_size=8, hidden=(96, 64), final_std=0.03)
         f, D = affine_flow(nfa, spec), 8
+    elif kind == "affine_general_ragged_k":
+        # first Linear K = 36 on the full-tile GEMM loop: its last k tile holds 4 of 32 columns, and the loads of the
+        # other 28 fetch the NEXT row's leading floats -- row 3's NaN in column 0 sits exactly there for row 2
+        spec = O.make_affine_spec(2, event_size=36, hidden=(128, 128), final_std=0.03)
+        f, D = affine_flow(nfa, spec), 36
     elif kind == "rqs_general":      # rqs_rows_kernel<8>
         spec = O.make_rqs_spec(2, event_size=6, hidden=(64, 64), num_bins=8, range_min=-4.0, range_max=4.0,
                                final_std=0.1)
@@ -960,7 +969,7 @@ def test_non_finite_inputs_stay_in_their_rows(nfa, kind, mode):
     except NFError:
         assert kind == "split" and mode == "bf16x3"
         return
-    if kind.startswith("rqs_general") or kind == "affine_general":
+    if kind.startswith("rqs_general") or kind.startswith("affine_general"):
         assert f.kernel_name == "generic_gemm"
     x = (rng.standard_normal((300, D)) * 1.5).astype(np.float32)
     clean = f.log_prob(x)
