@@ -300,7 +300,7 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
                                                                   __uint_as_float(rw[e][2]), __uint_as_float(rw[e][3]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores above are invisible to the compiler's counters
   };
-#undef NF_A_PAIR_UNUSED
+#undef NF_A_PAIR
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
