@@ -26,7 +26,6 @@ struct Params {
   float range_min, range_max, min_bin, min_slope, slope_offset;
   // waves of a workgroup that take sample groups (the others only help staging the layer images): small
   // batches spread over more workgroups instead of filling one.  0 = all of them.
-  int active_waves = 0;
 };
 
 __device__ __forceinline__ float swap_halves(float v) {

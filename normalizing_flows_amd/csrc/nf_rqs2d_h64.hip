@@ -106,9 +106,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
   const int i = lane & 31, h = lane >> 5;
   const long long rows = io.rows;
   const long long groups = (rows + (T * 32 - 1)) / (T * 32);
-  const int aw = p.active_waves > 0 ? p.active_waves : WAVES;
-  const long long groups_per_pass = (long long)gridDim.x * aw;
-  const long long passes = (groups + groups_per_pass - 1) / groups_per_pass;  // same for every block
+  // Passes (same count for every block): full ones -- every wave of every block has a group -- then one that deals
+  // the remaining groups evenly: aw_last live waves per block (waves 0 .. aw_last-1: one per SIMD first), so every
+  // SIMD of the chip ends up with the same number of groups whenever 1024 divides them.  A batch smaller than one
+  // full pass is the last pass alone: one group per workgroup before any workgroup gets two.
+  const long long groups_per_pass = (long long)gridDim.x * WAVES;
+  const long long full_passes = groups / groups_per_pass;
+  const long long groups_left = groups - full_passes * groups_per_pass;
+  const int aw_last = (int)((groups_left + gridDim.x - 1) / gridDim.x);
+  const long long passes = full_passes + (groups_left > 0 ? 1 : 0);
   const float2* __restrict__ xin = reinterpret_cast<const float2*>(io.x);
 
   auto layer_of = [&](int li) { return io.descending ? io.layer_end - 1 - li : io.layer_begin + li; };
@@ -143,8 +149,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
   long long step = 0;  // layers walked so far by this block: selects the LDS buffer
   for (long long pass = 0; pass < passes; ++pass) {
     // a wave without a group of its own walks the layers' barriers and staging only
-    const bool live = wave < aw && (pass * gridDim.x + blockIdx.x) * aw + wave < groups;
-    const long long g = live ? (pass * gridDim.x + blockIdx.x) * aw + wave : groups;
+    const bool last = pass >= full_passes;
+    const long long g_mine = last ? full_passes * groups_per_pass + (long long)blockIdx.x * aw_last + wave
+                                  : (pass * gridDim.x + blockIdx.x) * WAVES + wave;
+    const bool live = last ? (wave < aw_last && g_mine < groups) : true;
+    const long long g = live ? g_mine : groups;
     const int c_first = (p.first_mask_parity + layer_of(0)) & 1;
     float xc[T], xt[T], ld[T];
     long long idx[T];
@@ -344,10 +353,9 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   // few groups: one per workgroup first (every CU gets a wave before any CU gets two), then more waves each
   long long aw = (groups + max_grid() - 1) / max_grid();
   aw = aw < 1 ? 1 : (aw > waves ? waves : aw);
-  p.active_waves = (int)aw;
   long long want = (groups + aw - 1) / aw;
-  // 8-wave workgroups use 67.6 KB of LDS and <= 128 VGPRs: two of them share a CU
-  const int cap = waves == 8 ? 2 * max_grid() : max_grid();
+  // 8-wave workgroups of one tile per wave use 63.4 KB of LDS and <= 128 VGPRs: two of them share a CU
+  const int cap = (waves == 8 && T == 1) ? 2 * max_grid() : max_grid();
   const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
   switch (d.rqs_bins) {
