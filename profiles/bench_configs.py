@@ -86,7 +86,7 @@ if "d" in which:   # configs[4]: MNIST shape, 6 layers, batch 2^16
     lp32 = None
     for mode in ("f32", "bf16x3"):
         f.set_option("hidden_matmul", mode)
-        ms, out = time_log_prob(f, xd, rows, steps=2, warm=1)
+        ms, out = time_log_prob(f, xd, rows, steps=int(os.environ.get("NF_BENCH_STEPS", 2)), warm=1)
         lp = out.to_numpy()
         if lp32 is None:
             lp32 = lp
