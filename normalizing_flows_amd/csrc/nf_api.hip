@@ -269,22 +269,17 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid, boo
     if (f->path == PATH_RQS2D_H64) return rqs2d_x3::launch(f->d_wimg_x3, f->desc, io, f->stream, out_grid);
     return affine2d_x3::launch(f->d_wimg_x3, f->desc.first_mask_parity, io, f->stream, out_grid);
   }
-  if (f->path == PATH_SPLIT2D_SMALL) {
-    return split2d::launch(f->d_wimg, f->desc.hidden[0], f->desc.activation,
-                           f->desc.first_mask_parity, io, f->stream, out_grid);
-  }
-  if (f->path == PATH_RQS2D_H64) return rqs2d::launch(f->d_wimg, f->desc, io, f->stream, out_grid);
-  if (f->path == PATH_AFFINE2D_H64) {
+  // Kernels that keep the walked layers' weights in LDS take a bounded number of layers per launch: longer walks
+  // are several launches, state carried in device scratch.
+  auto segmented = [&](int max_layers, auto&& launch_one) -> int {
     const int nlay = io.layer_end - io.layer_begin;
-    if (nlay <= affine2d::kMaxResidentLayers)
-      return affine2d::launch(f->d_wimg, f->desc.first_mask_parity, io, 0, f->stream, out_grid);
-    // more layers than fit in LDS: several launches, state carried in device scratch
+    if (nlay <= max_layers) return launch_one(io);
     NF_TRY(ensure_stage(f, io.rows));
     const float* cur_x = io.x;
     const float* cur_ld = io.logdet_in;
     int done = 0;
     while (done < nlay) {
-      const int n = std::min(affine2d::kMaxResidentLayers, nlay - done);
+      const int n = std::min(max_layers, nlay - done);
       const bool last = done + n == nlay;
       ChainIO seg = io;
       if (io.descending) { seg.layer_end = io.layer_end - done; seg.layer_begin = seg.layer_end - n; }
@@ -295,13 +290,23 @@ static int run_chain_device(nf_flow* f, const ChainIO& io_in, int* out_grid, boo
         seg.y = f->d_y; seg.logdet_out = f->d_ld; seg.logprob_out = nullptr;
         seg.block_sums = nullptr; seg.add_base = 0;
       }
-      NF_TRY(affine2d::launch(f->d_wimg, f->desc.first_mask_parity, seg, 0, f->stream, out_grid));
+      NF_TRY(launch_one(seg));
       cur_x = f->d_y;
       cur_ld = f->d_ld;
       done += n;
     }
     return NF_OK;
-  }
+  };
+  if (f->path == PATH_SPLIT2D_SMALL)
+    return segmented(split2d::max_layers_per_launch(f->desc.hidden[0]), [&](const ChainIO& seg) {
+      return split2d::launch(f->d_wimg, f->desc.hidden[0], f->desc.activation, f->desc.first_mask_parity, seg,
+                             f->stream, out_grid);
+    });
+  if (f->path == PATH_RQS2D_H64) return rqs2d::launch(f->d_wimg, f->desc, io, f->stream, out_grid);
+  if (f->path == PATH_AFFINE2D_H64)
+    return segmented(affine2d::kMaxResidentLayers, [&](const ChainIO& seg) {
+      return affine2d::launch(f->d_wimg, f->desc.first_mask_parity, seg, 0, f->stream, out_grid);
+    });
   return run_chain_plan(f, io, out_grid);
 }
 

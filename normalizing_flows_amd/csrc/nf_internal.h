@@ -175,6 +175,7 @@ __host__ __device__ inline int layer_floats(int H) { return 4 * H + 2; }
 int launch(const float* wimg, int H, int activation, int first_flip, const ChainIO& io,
            hipStream_t stream, int* out_grid);
 int max_grid();
+int max_layers_per_launch(int H);  // the walked layers' weights are resident in LDS
 // training step (src/real_nvp.py:295-306): one backward launch per layer + its gradient gather
 bool bwd_supported(int H);
 int bwd_max_blocks();

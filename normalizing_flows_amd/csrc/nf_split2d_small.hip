@@ -2,67 +2,87 @@
 // MLP 1 -> H -> 2 (variant A of the reference: src/real_nvp.py:71-171, chain
 // order src/real_nvp.py:228-283, base density src/real_nvp.py:57-68).
 //
-// 12 FMA per sample per layer: there is no matrix work here.  One lane carries
-// two samples (one 16-byte load), the 4H+2 weights of a layer are wave-uniform
-// and come through the scalar cache (s_load), so the inner loop is pure VALU
-// with SGPR operands: per sample and layer 5 VALU per hidden unit + a
-// 6-instruction exp + 3.  Bound: VALU issue (HBM traffic is 12 B per sample),
-// see DESIGN.md.
+// 12 FMA per sample per layer: there is no matrix work here, the kernel is bound by vector issue (HBM traffic
+// is 12 B per sample).  What the vector ALU charges on gfx950 depends on the operand FORM
+// (profiles/microbench/valu_f32_operands.hip, 8 waves per SIMD): v_fma / v_mul / v_add with VGPR operands 2.5-3.3
+// cycles per wave64 instruction, the same opcodes with an SGPR operand 4.1-4.4, v_max 4.2, v_exp 8.2.  Hence:
+//   * the walked layers' weights are staged ONCE per workgroup in LDS, four floats per hidden unit
+//     (w0, b0, w_shift, w_logscale * log2 e): one 16-byte broadcast read per unit brings them into VGPRs -- no SGPR
+//     operands, no moves, and nothing on the vector-memory counter, so
+//   * the next samples of a lane are requested before the current ones are walked and that request stays in
+//     flight across the whole walk (first build: weights through vector loads with a wait per layer pair that
+//     also waited for the samples -- the vector ALU was busy half of the time, 184 us at 2^24 rows);
+//   * the log-scale comes out of the conditioner in units of log 2 (weights and bias prescaled when staged), so
+//     exp(log_scale) is ONE v_exp_f32 and the log-det is summed in those units and scaled by ln 2 once per sample
+//     (the two-float product that makes exp2(x * log2 e) accurate cost 5 instructions per sample and layer;
+//     prescaling rounds each weight once, the same order of error as log_scale's own float32 rounding);
+//   * a lane carries two samples (one 16-byte load); the LDS reads of a layer are shared by them.
+// Measured at 2^24 rows (profiles/bench_configs.py a): 184 us -> 96 us, vector ALU 94 % busy at 4.2 cycles per
+// instruction (profiles/r02/config_a_pmc_summary.json); per sample and layer the kernel issues 21 instructions
+// (4 x (fma, mul, max, 2 fma) + exp + 4), the operand-form table prices them at 79 cycles, the kernel spends 98.
 #include "nf_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace nf {
 namespace split2d {
 
 struct Params {
-  const float* wimg;  // [L][4H+2]: w0[H], b0[H], w1[H][2], b1[2]
   ChainIO io;
   int H;
   int first_flip;  // flip of layer 0
 };
 
+// LDS image of one layer: [H] x {w0, b0, w_shift, w_logscale * log2 e}, then {b_shift, b_logscale * log2 e, 0, 0}
+__host__ __device__ inline int lds_layer_floats(int H) { return 4 * H + 4; }
+constexpr int kMaxLdsFloats = 15 * 1024;  // 60 KB of weights per launch
+
+int max_layers_per_launch(int H) { return kMaxLdsFloats / lds_layer_floats(H); }
+
+// exp for the backward walk: 2^(x*log2 e) with the product carried in two floats (see nf_affine2d_h64.hip)
 __device__ __forceinline__ float exp_f32(float x) {
-  // 2^(x*log2 e) with the product carried in two floats (see nf_affine2d_h64.hip)
-  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float kLog2eHi = 1.44269502e+00f, kLog2eLo = 1.92596299e-08f, kLn2f = 6.93147182e-01f;
   const float hi = x * kLog2eHi;
   const float lo = fmaf(x, kLog2eLo, fmaf(x, kLog2eHi, -hi));
   const float e = __builtin_amdgcn_exp2f(hi);
-  return fmaf(e, lo * kLn2, e);
+  return fmaf(e, lo * kLn2f, e);
 }
 
-// one coupling layer on two samples: c* condition, t* are transformed
-template <int LEAKY, int INV, int HT>
-__device__ __forceinline__ void layer(const float* __restrict__ w, int Hrt, float ca, float cb, float& ta, float& tb,
-                                      float& lda, float& ldb) {
+constexpr float kLog2e = 1.44269504088896341f;
+constexpr float kLn2 = 0.69314718055994531f;
+
+// one coupling layer on S samples: c conditions, t is transformed, ld2 = log-det in units of log 2
+template <int LEAKY, int INV, int HT, int S>
+__device__ __forceinline__ void layer(const float* __restrict__ w, int Hrt, const float (&c)[S], float (&t)[S],
+                                      float (&ld2)[S]) {
   const int H = HT > 0 ? HT : Hrt;
-  float sa = 0.f, la = 0.f, sb = 0.f, lb = 0.f;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
+  const float2 bias = *reinterpret_cast<const float2*>(w + 4 * H);
+  float sh[S], ls[S];
+#pragma unroll
+  for (int u = 0; u < S; ++u) { sh[u] = bias.x; ls[u] = bias.y; }
 #pragma unroll 4
   for (int k = 0; k < H; ++k) {
-    const float w0 = w[k], b0 = w[H + k], ws = w[2 * H + 2 * k], wl = w[2 * H + 2 * k + 1];
-    float a = fmaf(ca, w0, b0), b = fmaf(cb, w0, b0);
-    if (LEAKY) {  // jax.nn.leaky_relu, slope 0.01 < 1: max(v, 0.01 v)  (src/real_nvp.py:167)
-      a = fmaxf(a, 0.01f * a);
-      b = fmaxf(b, 0.01f * b);
-    } else {
-      a = fmaxf(a, 0.f);
-      b = fmaxf(b, 0.f);
+    const float4 wk = w4[k];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      float a = fmaf(c[u], wk.x, wk.y);
+      // jax.nn.leaky_relu, slope 0.01 < 1: max(v, 0.01 v)  (src/real_nvp.py:167)
+      a = LEAKY ? fmaxf(a, 0.01f * a) : fmaxf(a, 0.f);
+      sh[u] = fmaf(a, wk.z, sh[u]);
+      ls[u] = fmaf(a, wk.w, ls[u]);
     }
-    sa = fmaf(a, ws, sa); la = fmaf(a, wl, la);
-    sb = fmaf(b, ws, sb); lb = fmaf(b, wl, lb);
   }
-  const float bs = w[4 * H], bl = w[4 * H + 1];
-  sa += bs; la += bl; sb += bs; lb += bl;
-  if (INV) {
-    ta = (ta - sa) * exp_f32(-la);  // src/real_nvp.py:129
-    tb = (tb - sb) * exp_f32(-lb);
-    lda -= la;                      // src/real_nvp.py:157
-    ldb -= lb;
-  } else {
-    ta = fmaf(ta, exp_f32(la), sa);  // src/real_nvp.py:96
-    tb = fmaf(tb, exp_f32(lb), sb);
-    lda += la;
-    ldb += lb;
+#pragma unroll
+  for (int u = 0; u < S; ++u) {
+    if (INV) {
+      t[u] = (t[u] - sh[u]) * __builtin_amdgcn_exp2f(-ls[u]);  // src/real_nvp.py:129
+      ld2[u] -= ls[u];                                          // src/real_nvp.py:157
+    } else {
+      t[u] = fmaf(t[u], __builtin_amdgcn_exp2f(ls[u]), sh[u]);  // src/real_nvp.py:96
+      ld2[u] += ls[u];
+    }
   }
 }
 
@@ -79,56 +99,114 @@ __device__ __forceinline__ float finish(const ChainIO& io, float v0, float v1, f
   return lp;
 }
 
-template <int LEAKY, int INV, int HT>
-__global__ __launch_bounds__(256) void chain_kernel(Params p) {
+// S = 2 * V samples per lane: V 16-byte loads {x0, y0, x1, y1}
+template <int LEAKY, int INV, int HT, int V>
+__global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __restrict__ wimg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int S = 2 * V;
   const ChainIO& io = p.io;
   const long long rows = io.rows;
-  const long long pairs = (rows + 1) / 2;
+  const long long groups = (rows + S - 1) / S;
   const int H = HT > 0 ? HT : p.H;
-  const int stride = layer_floats(H);
   const int nlay = io.layer_end - io.layer_begin;
-  double sum = 0.0;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < pairs;
-       q += (long long)gridDim.x * 256) {
-    const long long r0 = 2 * q;
-    const bool two = r0 + 1 < rows;
-    float4 v;
-    if (two) {
-      v = reinterpret_cast<const float4*>(io.x)[q];
+  const int SL = lds_layer_floats(H);
+
+  // stage the walked layers (global image per layer: w0[H], b0[H], w1[H][2], b1[2])
+  for (int idx = threadIdx.x; idx < nlay * SL; idx += 256) {
+    const int li = idx / SL, r = idx - li * SL;
+    const float* __restrict__ src = wimg + (size_t)(io.layer_begin + li) * layer_floats(H);
+    const int k = r >> 2, e = r & 3;
+    float v;
+    if (k < H) v = e == 0 ? src[k] : e == 1 ? src[H + k] : src[2 * H + 2 * k + (e - 2)];
+    else v = e < 2 ? src[4 * H + e] : 0.f;
+    if (e == 3 || (k == H && e == 1)) v *= kLog2e;
+    lds[idx] = v;
+  }
+  __syncthreads();
+
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(io.x);
+  // samples S*g .. S*g + S-1 of group g as V float4 {x, y, x, y}; a group that runs past the last row is read
+  // sample by sample
+  auto fetch = [&](long long g, float4 (&v)[V]) {
+    if (S * g + S <= rows) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = x4[V * g + j];
     } else {
-      const float2 s = reinterpret_cast<const float2*>(io.x)[r0];
-      v = make_float4(s.x, s.y, 0.f, 0.f);
+      const float2* __restrict__ x2 = reinterpret_cast<const float2*>(io.x);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const long long r0 = S * g + 2 * j;
+        const float2 a = r0 < rows ? x2[r0] : make_float2(0.f, 0.f);
+        const float2 b = r0 + 1 < rows ? x2[r0 + 1] : make_float2(0.f, 0.f);
+        v[j] = make_float4(a.x, a.y, b.x, b.y);
+      }
     }
-    float lda = io.logdet_in ? io.logdet_in[r0] : 0.f;
-    float ldb = (io.logdet_in && two) ? io.logdet_in[r0 + 1] : 0.f;
+  };
+
+  double sum = 0.0;
+  const long long gstride = (long long)gridDim.x * 256;
+  long long gn = (long long)blockIdx.x * 256 + threadIdx.x;
+  float4 vn[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) vn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gn < groups) fetch(gn, vn);
+  while (gn < groups) {
+    const long long g = gn;
+    float d0[S], d1[S], ld2[S];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      d0[2 * j] = vn[j].x; d1[2 * j] = vn[j].y; d0[2 * j + 1] = vn[j].z; d1[2 * j + 1] = vn[j].w;
+    }
+    gn += gstride;
+    if (gn < groups) fetch(gn, vn);  // stays in flight while this group's layers are walked
+#pragma unroll
+    for (int u = 0; u < S; ++u) ld2[u] = 0.f;
+
     // flips alternate, so layers are walked in pairs with fixed roles; an odd one first
     int li = 0;
     int l = io.descending ? io.layer_end - 1 : io.layer_begin;
     const int step = io.descending ? -1 : 1;
+    const float* L = lds + (l - io.layer_begin) * SL;
+    const int Lstep = step * SL;
     if (((l & 1) ^ p.first_flip) != 0) {  // flipped layer: dim 1 conditions, dim 0 is transformed
-      layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.y, v.w, v.x, v.z, lda, ldb);
-      l += step;
+      layer<LEAKY, INV, HT, S>(L, H, d1, d0, ld2);
+      L += Lstep;
       ++li;
     }
     for (; li + 1 < nlay; li += 2) {
-      layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.x, v.z, v.y, v.w, lda, ldb);
-      layer<LEAKY, INV, HT>(p.wimg + (size_t)(l + step) * stride, H, v.y, v.w, v.x, v.z, lda, ldb);
-      l += 2 * step;
+      layer<LEAKY, INV, HT, S>(L, H, d0, d1, ld2);
+      layer<LEAKY, INV, HT, S>(L + Lstep, H, d1, d0, ld2);
+      L += 2 * Lstep;
     }
-    if (li < nlay) layer<LEAKY, INV, HT>(p.wimg + (size_t)l * stride, H, v.x, v.z, v.y, v.w, lda, ldb);
+    if (li < nlay) layer<LEAKY, INV, HT, S>(L, H, d0, d1, ld2);
 
-    const float lpa = finish(io, v.x, v.y, lda);
-    const float lpb = finish(io, v.z, v.w, ldb);
-    if (two) {
-      if (io.y) reinterpret_cast<float4*>(io.y)[q] = v;
-      if (io.logdet_out) reinterpret_cast<float2*>(io.logdet_out)[q] = make_float2(lda, ldb);
-      if (io.logprob_out) reinterpret_cast<float2*>(io.logprob_out)[q] = make_float2(lpa, lpb);
-      sum += (double)lpa + (double)lpb;
+    const long long r0 = S * g;
+    const bool full = r0 + S <= rows;
+    float ld[S], lp[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      const float in = (io.logdet_in && r0 + u < rows) ? io.logdet_in[r0 + u] : 0.f;
+      ld[u] = fmaf(ld2[u], kLn2, in);
+      lp[u] = finish(io, d0[u], d1[u], ld[u]);
+    }
+    if (full) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (io.y) reinterpret_cast<float4*>(io.y)[V * g + j] = make_float4(d0[2 * j], d1[2 * j], d0[2 * j + 1], d1[2 * j + 1]);
+        if (io.logdet_out) reinterpret_cast<float2*>(io.logdet_out)[V * g + j] = make_float2(ld[2 * j], ld[2 * j + 1]);
+        if (io.logprob_out) reinterpret_cast<float2*>(io.logprob_out)[V * g + j] = make_float2(lp[2 * j], lp[2 * j + 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < S; ++u) sum += (double)lp[u];
     } else {
-      if (io.y) reinterpret_cast<float2*>(io.y)[r0] = make_float2(v.x, v.y);
-      if (io.logdet_out) io.logdet_out[r0] = lda;
-      if (io.logprob_out) io.logprob_out[r0] = lpa;
-      sum += (double)lpa;
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+        if (r0 + u < rows) {
+          if (io.y) reinterpret_cast<float2*>(io.y)[r0 + u] = make_float2(d0[u], d1[u]);
+          if (io.logdet_out) io.logdet_out[r0 + u] = ld[u];
+          if (io.logprob_out) io.logprob_out[r0 + u] = lp[u];
+          sum += (double)lp[u];
+        }
     }
   }
   if (io.block_sums) {
@@ -141,12 +219,25 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p) {
   }
 }
 
+// two resident rounds of 8 workgroups of 4 waves per CU (measured at 2^24 rows: 1024 / 2048 / 4096 workgroups
+// 115 / 101 / 96 us with two samples per lane, 101 / 96 / 96 us with four)
 int max_grid() { return 4096; }
 
-template <int LEAKY, int INV>
-static void launch_h(const Params& p, int grid, hipStream_t stream) {
-  if (p.H == 4) hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 4>), dim3(grid), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 0>), dim3(grid), dim3(256), 0, stream, p);
+template <int LEAKY, int INV, int V>
+static void launch_h(const Params& p, const float* wimg, int grid, size_t lds_bytes, hipStream_t stream) {
+  if (p.H == 4) hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 4, V>), dim3(grid), dim3(256), lds_bytes, stream, p, wimg);
+  else hipLaunchKernelGGL((chain_kernel<LEAKY, INV, 0, V>), dim3(grid), dim3(256), lds_bytes, stream, p, wimg);
+}
+
+template <int V>
+static void launch_v(const Params& p, const float* wimg, bool leaky, int grid, size_t lds_bytes, hipStream_t stream) {
+  if (leaky) {
+    if (p.io.inverse_op) launch_h<1, 1, V>(p, wimg, grid, lds_bytes, stream);
+    else launch_h<1, 0, V>(p, wimg, grid, lds_bytes, stream);
+  } else {
+    if (p.io.inverse_op) launch_h<0, 1, V>(p, wimg, grid, lds_bytes, stream);
+    else launch_h<0, 0, V>(p, wimg, grid, lds_bytes, stream);
+  }
 }
 
 int launch(const float* wimg, int H, int activation, int first_flip, const ChainIO& io,
@@ -155,18 +246,29 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
     set_error("split2d kernel supports hidden width 1..%d, got %d", kMaxHidden, H);
     return NF_ERR_UNSUPPORTED;
   }
+  const int nlay = io.layer_end - io.layer_begin;
+  if (nlay > max_layers_per_launch(H)) {
+    set_error("split2d kernel walks at most %d layers of width %d per launch, got %d", max_layers_per_launch(H), H, nlay);
+    return NF_ERR_UNSUPPORTED;
+  }
   Params p;
-  p.wimg = wimg;
   p.io = io;
   p.H = H;
   p.first_flip = first_flip & 1;
   const bool leaky = activation == NF_ACT_LEAKY_RELU;
-  const long long pairs = (io.rows + 1) / 2;
-  long long want = (pairs + 255) / 256;
-  const int grid = (int)(want < 1 ? 1 : (want > max_grid() ? max_grid() : want));
+  const size_t lds_bytes = (size_t)nlay * lds_layer_floats(H) * sizeof(float);
+  // two samples per lane; four (NF_SPLIT2D_SAMPLES=4, development knob) share a layer's LDS reads between more
+  // samples but measure the same: the kernel is bound by vector issue, not by LDS or latency
+  int S = 2;
+  if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4) S = v; }
+  const long long groups = (io.rows + S - 1) / S;
+  long long want = (groups + 255) / 256;
+  int cap = max_grid();
+  if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= 4096) cap = v; }  // block_sums holds 4096
+  const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
-  if (leaky) { if (io.inverse_op) launch_h<1, 1>(p, grid, stream); else launch_h<1, 0>(p, grid, stream); }
-  else { if (io.inverse_op) launch_h<0, 1>(p, grid, stream); else launch_h<0, 0>(p, grid, stream); }
+  if (S == 4) launch_v<2>(p, wimg, leaky, grid, lds_bytes, stream);
+  else launch_v<1>(p, wimg, leaky, grid, lds_bytes, stream);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

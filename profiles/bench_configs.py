@@ -34,7 +34,7 @@ if "a" in which:   # src/real_nvp.py variant, 8 layers, batch 2^20 (and 2^24 to 
     cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
                           activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
     f = flow.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
-    for lg in (20, 24):
+    for lg in [int(v) for v in os.environ.get("NF_BENCH_A_LG", "20,24").split(",")]:
         rows = 1 << lg
         x = O.make_inputs("energy2", rows)
         xd = flow.DeviceArray.from_numpy(x)

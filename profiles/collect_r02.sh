@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 profile collection (run on the GPU box through gpurun; ~6 minutes):
 #   headline bench:  kernel trace + stats, then SEPARATE --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ sets)
-#   configs[2], [4]: the same on profiles/bench_configs.py c / d
+#   configs[2], [4]: the same on profiles/bench_configs.py c / d;  a: the src/real_nvp.py flow (variant A)
 # rocprofv3 gets the program itself after `--` (python3 ...), never a wrapper.  Summaries land in profiles/r02/
 # (profiles/summarize.py): <tag>_kernel_stats.csv = the --stats table, <tag>_pmc_summary.json = per-kernel counter
 # means with hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> B; reads doubled as MI355X_MICROARCH.md's HBM
@@ -29,6 +29,7 @@ for what in ${@:-bench c d}; do
            collect gpurun_out/prof_r02_bench r02/final_bench_n1 bench.py --steps 50 --warmup 10 --min-seconds 0 --no-cpu-baseline --no-variants --no-other-configs ;;
     c) collect gpurun_out/prof_r02_c r02/config_c profiles/bench_configs.py c ;;
     d) collect gpurun_out/prof_r02_d r02/config_d profiles/bench_configs.py d ;;
+    a) collect gpurun_out/prof_r02_a r02/config_a profiles/bench_configs.py a ;;
   esac
 done
 echo collected
