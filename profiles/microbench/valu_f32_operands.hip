@@ -17,6 +17,8 @@ __global__ void cost(float* out, int iters, float sc) {
     d[i] = threadIdx.x * 1e-3f + i; a[i] = 0.999f + i * 1e-4f; b[i] = 1e-3f * i;
     pd[i] = v2f{d[i], d[i]}; pa[i] = v2f{a[i], a[i]}; pb[i] = v2f{b[i], b[i]};
   }
+  double dd[CHAINS], da[CHAINS];
+  for (int i = 0; i < CHAINS; ++i) { dd[i] = d[i]; da[i] = a[i]; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < REP; ++r)
@@ -40,10 +42,19 @@ __global__ void cost(float* out, int iters, float sc) {
         else if (OP == 15) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(d[i]) : "v"(a[i]));
         else if (OP == 16) asm volatile("v_mul_legacy_f32 %0, %1, %0" : "+v"(d[i]) : "v"(a[i]));
         else if (OP == 17) asm volatile("v_fma_f32 %0, |%1|, %2, %0" : "+v"(d[i]) : "v"(a[i]), "v"(b[i]));
+        else if (OP == 18) asm volatile("v_add_f64 %0, %1, %0" : "+v"(dd[i]) : "v"(da[i]));
+        else if (OP == 19) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(dd[i]) : "v"(da[i]));
+        else if (OP == 20) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd[i]) : "v"(d[i]));
+        else if (OP == 21) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(d[i]) : "v"(dd[i]));
+        else if (OP == 22) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(dd[i]) : "v"(da[i]));
+        else if (OP == 23) asm volatile("v_log_f32 %0, %0" : "+v"(d[i]));
+        else if (OP == 24) asm volatile("v_rcp_f32 %0, %0" : "+v"(d[i]));
+        else if (OP == 25) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %1, %0, vcc" : "+v"(d[i]) : "v"(a[i]) : "vcc");
+        else if (OP == 26) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(d[i]) : "v"(a[i]) : "vcc");
       }
   }
   float s = 0;
-  for (int i = 0; i < CHAINS; ++i) s += d[i] + pd[i].x + pd[i].y;
+  for (int i = 0; i < CHAINS; ++i) s += d[i] + pd[i].x + pd[i].y + (float)dd[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -77,11 +88,19 @@ int main() {
   run("v_add_f32 d, a, d", cost<7>);
   run("v_sub_f32 d, a, d", cost<15>);
   run("v_mul_f32 d, s, d (SGPR)", cost<8>);
-  run("v_cndmask_b32 d, a, d, vcc", cost<11>);
   run("v_med3_f32 d, a, b, d", cost<12>);
   run("v_fma_f32 d, a, b, d clamp", cost<13>);
   run("v_mul_f32 d, a, d clamp", cost<14>);
   run("v_mul_legacy_f32 d, a, d", cost<16>);
   run("v_fma_f32 d, |a|, b, d", cost<17>);
+  run("v_add_f64 d, a, d", cost<18>);
+  run("v_fma_f64 d, a, a, d", cost<19>);
+  run("v_mul_f64 d, a, d", cost<22>);
+  run("v_cvt_f64_f32", cost<20>);
+  run("v_cvt_f32_f64", cost<21>);
+  run("v_log_f32", cost<23>);
+  run("v_rcp_f32", cost<24>);
+  run("v_cmp_ge_f32 + v_cndmask_b32 (pair)", cost<25>);
+  run("v_cmp_ge_f32 + v_addc_co_u32 (pair)", cost<26>);
   return 0;
 }

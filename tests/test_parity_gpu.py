@@ -432,15 +432,27 @@ def test_split_log_prob(nfa, density):
     assert_close(f.log_prob(x), O.a_log_prob_chain(params, flips, x), f"A log_prob {density}")
 
 
-@pytest.mark.parametrize("L,H,rows", [(1, 4, 1), (2, 4, 2), (3, 7, 255), (8, 16, 513), (11, 4, 10000)])
+# (61, 64, .): more layers than one launch keeps in LDS (59 at width 64): two launches, the second starts on a flipped layer
+@pytest.mark.parametrize("L,H,rows", [(1, 4, 1), (2, 4, 2), (3, 7, 255), (8, 16, 513), (11, 4, 10000), (61, 64, 301)])
 def test_split_shapes(nfa, L, H, rows):
     params, flips = O.make_a_params(L, sizes=(1, H, 2))
     for net in params:  # non-zero biases so they are exercised
         for j, (W, b) in enumerate(net):
             net[j][1] = (np.arange(b.size) * 0.01 - 0.02).astype(np.float32)
+            if L > 59:  # a deep, wide chain: keep every layer close to the identity
+                net[j][0] = (W * 0.25).astype(np.float32)
+                net[j][1] = (net[j][1] * 0.1).astype(np.float32)
     f = split_flow(nfa, params)
     x = O.make_inputs("energy2", rows, seed=rows)
     assert_close(f.log_prob(x), O.a_log_prob_chain(params, flips, x), "A shapes")
+    assert abs(f.nll(x) - O.a_nll(params, flips, x)) <= 1e-5 * max(1.0, abs(O.a_nll(params, flips, x)))
+    if L > 59:  # the generative walk of the segmented chain and its way back
+        from normalizing_flows_amd import _lib
+        z = np.random.default_rng(L).standard_normal((rows, 2)).astype(np.float32)
+        y, _ = f.chain_apply(_lib.DIR_FIRST_TO_LAST_FORWARD, z)
+        assert_close(y, O.a_sample_chain_from_z(params, flips, z), "A sample chain, segmented")
+        back, _ = f.chain_apply(_lib.DIR_LAST_TO_FIRST_INVERSE, y)
+        assert np.abs(back - z).max() <= 1e-4
 
 
 def test_split_sampling_direction_and_layers(nfa):
