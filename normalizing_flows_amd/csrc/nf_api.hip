@@ -1097,7 +1097,7 @@ static int ensure_train(nf_flow* f, long long rows) {
     NF_HIP(hipMalloc(&t.d_v, n * sizeof(float)));
     NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
     NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
-    NF_HIP(hipMalloc(&t.d_partials, (size_t)split2d::bwd_max_blocks() * split2d::layer_floats(d.hidden[0]) * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_partials, (size_t)split2d::bwd_max_blocks() * d.num_layers * split2d::layer_floats(d.hidden[0]) * sizeof(float)));
     t.step = 0;
     if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     t.ready = true;
@@ -1196,11 +1196,9 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
     return NF_OK;
   }
   if (f->path == PATH_SPLIT2D_SMALL) {
-    const int H = d.hidden[0], per = split2d::layer_floats(H);
-    for (int l = 0; l < d.num_layers; ++l)
-      NF_TRY(split2d::launch_bwd_layer(f->d_wimg + (size_t)l * per, H, d.activation, t.d_state_v, t.d_state_g,
-                                       t.d_partials, t.d_grad + (size_t)l * per, rows_local, rows_global,
-                                       (l & 1) ^ d.first_mask_parity, l == 0, f->stream));
+    NF_TRY(split2d::launch_bwd_chain(f->d_wimg, d.hidden[0], d.num_layers, d.activation, d.first_mask_parity,
+                                     t.d_state_v, t.d_state_g, t.d_partials, t.d_grad, rows_local, rows_global,
+                                     f->stream));
     if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
     return NF_OK;
   }

@@ -176,12 +176,11 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
            hipStream_t stream, int* out_grid);
 int max_grid();
 int max_layers_per_launch(int H);  // the walked layers' weights are resident in LDS
-// training step (src/real_nvp.py:295-306): one backward launch per layer + its gradient gather
+// training step (src/real_nvp.py:295-306): the backward walk of the whole chain + one gradient gather
 bool bwd_supported(int H);
 int bwd_max_blocks();
-int launch_bwd_layer(const float* w_layer, int H, int activation, float* v, float* G, float* partials,
-                     float* grad_layer, long long rows, long long rows_global, int flip, int first,
-                     hipStream_t stream);
+int launch_bwd_chain(const float* wimg, int H, int num_layers, int activation, int first_flip, float* v, float* G,
+                     float* partials, float* grad, long long rows, long long rows_global, hipStream_t stream);
 }  // namespace split2d
 
 // ---- path 3: general path (GEMM chain + transform kernels), any D / widths / kind ---

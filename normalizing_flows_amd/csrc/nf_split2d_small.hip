@@ -275,59 +275,82 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
 
 
 // ---------------------------------------------------------------------------
-// Backward of one split coupling layer (training step of src/real_nvp.py:295-306:
-// jax.value_and_grad(loss) + p - lr * g).  Like the masked flow's backward it stores no
-// activations: the walk starts from z and rebuilds each layer's input with forward_nvp while the
-// 12-FMA conditioner is recomputed.  One launch per layer, state (v, G) in HBM, the 4H+2
-// gradient accumulators of a thread in registers, fixed-order reduction to one partial per block.
-// loss_i = |z|^2/2 + log(2 pi) + sum(log_scale)  (log_prob = base - sum log_scale, :157-158)
+// Backward of the chain (training step of src/real_nvp.py:295-306: jax.value_and_grad(loss) + p - lr * g).
+// Like the masked flow's backward it stores no activations: the walk starts from z and rebuilds each layer's
+// input with forward_nvp while the 12-FMA conditioner is recomputed.
+//   loss_i = |z|^2/2 + log(2 pi) + sum(log_scale)      (log_prob = base - sum log_scale, :157-158)
+// ONE launch walks up to LG layers with a sample's state (value, gradient) in registers and the 4H+2 gradient
+// accumulators of every walked layer in registers too (LG = 8 / 4 / 2 for H = 4 / 8 / 16: ~140 of them); longer
+// chains are several launches with the state carried through HBM.  The first build launched one kernel per layer
+// (state through HBM every time: 32 B per sample and layer, 112 us per layer at 2^24 rows, at the HBM roofline)
+// plus a gather per layer whose 4H+2 threads added the blocks' partials one dependent load at a time (84 us per
+// layer whatever the batch: 90 % of the step at 2^17 rows).  Sums are in a fixed order throughout: a thread's rows
+// in grid-stride order, lanes by a shuffle tree, the four waves, then the blocks (gather_kernel).
 // ---------------------------------------------------------------------------
-template <int H, int LEAKY>
-__global__ __launch_bounds__(256) void bwd_layer_kernel(const float* __restrict__ w, float2* __restrict__ v,
+template <int H, int LEAKY, int LG, int FLIP0>
+__global__ __launch_bounds__(256) void bwd_chain_kernel(const float* __restrict__ w, float2* __restrict__ v,
                                                         float2* __restrict__ G, float* __restrict__ partials,
-                                                        long long rows, int flip, int first) {
-  float dw0[H], db0[H], dw1s[H], dw1l[H];
-  float db1s = 0.f, db1l = 0.f;
+                                                        long long rows, int layer_begin, int nl, int nl_total,
+                                                        int first, int last) {
+  constexpr int N = 4 * H + 2;
+  float dw0[LG][H], db0[LG][H], dw1s[LG][H], dw1l[LG][H], db1s[LG], db1l[LG];
 #pragma unroll
-  for (int k = 0; k < H; ++k) { dw0[k] = 0.f; db0[k] = 0.f; dw1s[k] = 0.f; dw1l[k] = 0.f; }
+  for (int j = 0; j < LG; ++j) {
+    db1s[j] = 0.f; db1l[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < H; ++k) { dw0[j][k] = 0.f; db0[j][k] = 0.f; dw1s[j][k] = 0.f; dw1l[j][k] = 0.f; }
+  }
   for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
     const float2 s = v[r];
     const float2 g = first ? s : G[r];
-    const float c = flip ? s.y : s.x;      // conditioning half (unchanged by the layer)
-    const float x2 = flip ? s.x : s.y;     // the layer's OUTPUT on the transformed half
-    float Gc = flip ? g.y : g.x;
-    const float G2 = flip ? g.x : g.y;
-    float a[H], pre[H];
-    float shift = w[4 * H], ls = w[4 * H + 1];
+    float d[2] = {s.x, s.y}, gd[2] = {g.x, g.y};
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-      pre[k] = fmaf(c, w[k], w[H + k]);
-      a[k] = LEAKY ? fmaxf(pre[k], 0.01f * pre[k]) : fmaxf(pre[k], 0.f);
-      shift = fmaf(a[k], w[2 * H + 2 * k], shift);
-      ls = fmaf(a[k], w[2 * H + 2 * k + 1], ls);
-    }
-    const float einv = exp_f32(-ls);
-    const float y2 = fmaf(x2, exp_f32(ls), shift);   // the layer's input: forward_nvp (src/real_nvp.py:96)
-    const float g_s = -G2 * einv;                     // x2 = (y2 - shift) e^-ls
-    const float g_ls = fmaf(-G2, x2, 1.f);            // d x2 / d ls = -x2; +1 from the sum of log_scale
-    db1s += g_s;
-    db1l += g_ls;
+    for (int j = 0; j < LG; ++j) {
+      if (j < nl) {
+        constexpr int kC = 0;  // silence unused warnings in some instantiations
+        (void)kC;
+        const int ic = (FLIP0 ^ (j & 1)) ? 1 : 0;  // conditioning half (unchanged by the layer)
+        const int it = 1 - ic;                      // transformed half: d[it] is the layer's OUTPUT
+        const float* __restrict__ wl = w + (size_t)(layer_begin + j) * N;
+        const float c = d[ic], x2 = d[it], G2 = gd[it];
+        float Gc = gd[ic];
+        float a[H], pre[H];
+        float shift = wl[4 * H], ls = wl[4 * H + 1];
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-      dw1s[k] = fmaf(a[k], g_s, dw1s[k]);
-      dw1l[k] = fmaf(a[k], g_ls, dw1l[k]);
-      const float ga = fmaf(w[2 * H + 2 * k], g_s, w[2 * H + 2 * k + 1] * g_ls);
-      const float gp = LEAKY ? (pre[k] >= 0.f ? ga : 0.01f * ga) : (pre[k] > 0.f ? ga : 0.f);
-      dw0[k] = fmaf(gp, c, dw0[k]);
-      db0[k] += gp;
-      Gc = fmaf(gp, w[k], Gc);
+        for (int k = 0; k < H; ++k) {
+          pre[k] = fmaf(c, wl[k], wl[H + k]);
+          a[k] = LEAKY ? fmaxf(pre[k], 0.01f * pre[k]) : fmaxf(pre[k], 0.f);
+          shift = fmaf(a[k], wl[2 * H + 2 * k], shift);
+          ls = fmaf(a[k], wl[2 * H + 2 * k + 1], ls);
+        }
+        const float einv = exp_f32(-ls);
+        const float y2 = fmaf(x2, exp_f32(ls), shift);   // the layer's input: forward_nvp (src/real_nvp.py:96)
+        const float g_s = -G2 * einv;                     // x2 = (y2 - shift) e^-ls
+        const float g_ls = fmaf(-G2, x2, 1.f);            // d x2 / d ls = -x2; +1 from the sum of log_scale
+        db1s[j] += g_s;
+        db1l[j] += g_ls;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+          dw1s[j][k] = fmaf(a[k], g_s, dw1s[j][k]);
+          dw1l[j][k] = fmaf(a[k], g_ls, dw1l[j][k]);
+          const float ga = fmaf(wl[2 * H + 2 * k], g_s, wl[2 * H + 2 * k + 1] * g_ls);
+          const float gp = LEAKY ? (pre[k] >= 0.f ? ga : 0.01f * ga) : (pre[k] > 0.f ? ga : 0.f);
+          dw0[j][k] = fmaf(gp, c, dw0[j][k]);
+          db0[j][k] += gp;
+          Gc = fmaf(gp, wl[k], Gc);
+        }
+        d[it] = y2;
+        gd[it] = G2 * einv;
+        gd[ic] = Gc;
+      }
     }
-    const float Gy2 = G2 * einv;
-    v[r] = flip ? make_float2(y2, c) : make_float2(c, y2);
-    G[r] = flip ? make_float2(Gy2, Gc) : make_float2(Gc, Gy2);
+    if (!last) {
+      v[r] = make_float2(d[0], d[1]);
+      G[r] = make_float2(gd[0], gd[1]);
+    }
   }
   // block reduction in a fixed order: lanes (shuffle tree), then the four waves
-  __shared__ float red[4][4 * H + 2];
+  __shared__ float red[4][LG * N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto wsum = [](float x) {
 #pragma unroll
@@ -335,60 +358,75 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(const float* __restrict_
     return x;
   };
 #pragma unroll
-  for (int k = 0; k < H; ++k) {
-    const float s0 = wsum(dw0[k]), s1 = wsum(db0[k]), s2 = wsum(dw1s[k]), s3 = wsum(dw1l[k]);
-    if (lane == 0) { red[wave][k] = s0; red[wave][H + k] = s1; red[wave][2 * H + 2 * k] = s2; red[wave][2 * H + 2 * k + 1] = s3; }
+  for (int j = 0; j < LG; ++j) {
+    if (j < nl) {
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const float s0 = wsum(dw0[j][k]), s1 = wsum(db0[j][k]), s2 = wsum(dw1s[j][k]), s3 = wsum(dw1l[j][k]);
+        if (lane == 0) {
+          red[wave][j * N + k] = s0; red[wave][j * N + H + k] = s1;
+          red[wave][j * N + 2 * H + 2 * k] = s2; red[wave][j * N + 2 * H + 2 * k + 1] = s3;
+        }
+      }
+      const float t0 = wsum(db1s[j]), t1 = wsum(db1l[j]);
+      if (lane == 0) { red[wave][j * N + 4 * H] = t0; red[wave][j * N + 4 * H + 1] = t1; }
+    }
   }
-  const float t0 = wsum(db1s), t1 = wsum(db1l);
-  if (lane == 0) { red[wave][4 * H] = t0; red[wave][4 * H + 1] = t1; }
   __syncthreads();
-  if (threadIdx.x < 4 * H + 2)
-    partials[(size_t)blockIdx.x * (4 * H + 2) + threadIdx.x] =
-        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  for (int e = threadIdx.x; e < nl * N; e += 256)
+    partials[((size_t)blockIdx.x * nl_total + layer_begin) * N + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
-// grad[e] = (1/rows_global) * sum over blocks of partial[b][e], blocks added in order
+// grad[e] = (1/rows_global) * sum over blocks of partial[b][e]: one wave per element, lane t adds blocks
+// t, t + 64, ... in order (float64), the lanes are added by a shuffle tree -- a fixed order
 __global__ __launch_bounds__(64) void bwd_gather_kernel(const float* __restrict__ partials, int nparts, int n,
-                                                       float* __restrict__ grad, float inv_rows) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= n) return;
-  float s = 0.f, c = 0.f;
-  for (int b = 0; b < nparts; ++b) {
-    const float y = partials[(size_t)b * n + e] - c;
-    const float t = s + y;
-    c = (t - s) - y;
-    s = t;
-  }
-  grad[e] = s * inv_rows;
+                                                       float* __restrict__ grad, double inv_rows) {
+  const int e = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 64) s += (double)partials[(size_t)b * n + e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (threadIdx.x == 0) grad[e] = (float)(s * inv_rows);
 }
 
 int bwd_max_blocks() { return 512; }
 bool bwd_supported(int H) { return H == 4 || H == 8 || H == 16; }
+int bwd_layers_per_launch(int H) { return H == 4 ? 8 : H == 8 ? 4 : 2; }
 
-template <int H>
-static void launch_bwd_h(const float* w, float* v, float* G, float* partials, long long rows, int flip, int first,
-                         int leaky, int grid, hipStream_t stream) {
-  if (leaky)
-    hipLaunchKernelGGL((bwd_layer_kernel<H, 1>), dim3(grid), dim3(256), 0, stream, w, reinterpret_cast<float2*>(v),
-                       reinterpret_cast<float2*>(G), partials, rows, flip, first);
-  else
-    hipLaunchKernelGGL((bwd_layer_kernel<H, 0>), dim3(grid), dim3(256), 0, stream, w, reinterpret_cast<float2*>(v),
-                       reinterpret_cast<float2*>(G), partials, rows, flip, first);
+template <int H, int LG>
+static void launch_bwd_h(const float* w, float* v, float* G, float* partials, long long rows, int layer_begin, int nl,
+                         int nl_total, int flip0, int first, int last, int leaky, int grid, hipStream_t stream) {
+  float2* v2 = reinterpret_cast<float2*>(v);
+  float2* G2 = reinterpret_cast<float2*>(G);
+#define NF_BWD_LAUNCH(LK, FL) \
+  hipLaunchKernelGGL((bwd_chain_kernel<H, LK, LG, FL>), dim3(grid), dim3(256), 0, stream, w, v2, G2, partials, rows, \
+                     layer_begin, nl, nl_total, first, last)
+  if (leaky) { if (flip0) NF_BWD_LAUNCH(1, 1); else NF_BWD_LAUNCH(1, 0); }
+  else { if (flip0) NF_BWD_LAUNCH(0, 1); else NF_BWD_LAUNCH(0, 0); }
+#undef NF_BWD_LAUNCH
 }
 
-int launch_bwd_layer(const float* w_layer, int H, int activation, float* v, float* G, float* partials, float* grad_layer,
-                     long long rows, long long rows_global, int flip, int first, hipStream_t stream) {
+// Gradient of the NLL with respect to every layer's weights, into grad [num_layers][4H+2].  v: z on entry (the
+// forward walk's output), G: scratch of the same size; partials: [bwd_max_blocks()][num_layers][4H+2].
+int launch_bwd_chain(const float* wimg, int H, int num_layers, int activation, int first_flip, float* v, float* G,
+                     float* partials, float* grad, long long rows, long long rows_global, hipStream_t stream) {
   if (!bwd_supported(H)) { set_error("split2d backward is built for hidden width 4, 8, 16"); return NF_ERR_UNSUPPORTED; }
   const long long want = (rows + 255) / 256;
   const int grid = (int)(want < 1 ? 1 : (want > bwd_max_blocks() ? bwd_max_blocks() : want));
   const int leaky = activation == NF_ACT_LEAKY_RELU;
-  if (H == 4) launch_bwd_h<4>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
-  else if (H == 8) launch_bwd_h<8>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
-  else launch_bwd_h<16>(w_layer, v, G, partials, rows, flip, first, leaky, grid, stream);
-  NF_HIP(hipGetLastError());
-  const int n = layer_floats(H);
-  hipLaunchKernelGGL(bwd_gather_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, partials, grid, n, grad_layer,
-                     1.0f / (float)rows_global);
+  const int LG = bwd_layers_per_launch(H);
+  // the layer log_prob applied last is walked first: layer 0, then 1, ...
+  for (int lb = 0; lb < num_layers; lb += LG) {
+    const int nl = num_layers - lb < LG ? num_layers - lb : LG;
+    const int flip0 = ((lb & 1) ^ first_flip) & 1;
+    const int first = lb == 0, last = lb + nl == num_layers;
+    if (H == 4) launch_bwd_h<4, 8>(wimg, v, G, partials, rows, lb, nl, num_layers, flip0, first, last, leaky, grid, stream);
+    else if (H == 8) launch_bwd_h<8, 4>(wimg, v, G, partials, rows, lb, nl, num_layers, flip0, first, last, leaky, grid, stream);
+    else launch_bwd_h<16, 2>(wimg, v, G, partials, rows, lb, nl, num_layers, flip0, first, last, leaky, grid, stream);
+    NF_HIP(hipGetLastError());
+  }
+  const int n = num_layers * layer_floats(H);
+  hipLaunchKernelGGL(bwd_gather_kernel, dim3(n), dim3(64), 0, stream, partials, grid, n, grad, 1.0 / (double)rows_global);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the other BASELINE.json configs (device-resident inputs, HIP events on the handle's
 stream).  One JSON line per config; these are measurement notes, bench.py holds the contract line.
-    python3 profiles/bench_configs.py [a] [c] [d] [b4k]"""
+    python3 profiles/bench_configs.py [a] [c] [d] [b4k] [train] [traina] [trainc]"""
 import json
 import os
 import sys
@@ -124,6 +124,28 @@ if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densiti
                           "ms_stream": ms,
                           "ms_wall": wall, "samples_per_s": rows / ms * 1e3,
                           "TFLOPs_at_4x_forward": rows * 4 * 69632 / ms / 1e9}))
+
+if "traina" in which:   # the SGD step of src/real_nvp.py:295-306 (variant A: MLP 1-4-2, 8 layers)
+    from normalizing_flows_amd import training
+    params, flips = O.make_a_params(8)
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
+                          activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
+    f = flow.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
+    opt = training.sgd(1e-3)
+    for lg in [int(v) for v in os.environ.get("NF_TRAINA_LG", "7,17,20,24").split(",")]:
+        rows = 1 << lg
+        xd = flow.DeviceArray.from_numpy(O.make_inputs("energy2", rows))
+        for _ in range(3):
+            f.train_step(xd, opt, want_nll=False)
+        f.synchronize()
+        steps = 20
+        f.timer_start()
+        for _ in range(steps):
+            f.train_step(xd, opt, want_nll=False)
+        ms = f.timer_stop() / steps
+        f.synchronize()
+        print(json.dumps({"config": f"train step (fwd + bwd + SGD) variant A (MLP 1-4-2) L=8 batch=2^{lg}",
+                          "ms_stream": ms, "samples_per_s": rows / ms * 1e3}), flush=True)
 
 if "trainc" in which:   # `update` of src/maf_toy_densities.py:167-176 (spline flow, general backward)
     from normalizing_flows_amd import training

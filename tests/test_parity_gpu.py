@@ -917,7 +917,9 @@ def test_training_reduces_nll(nfa):
     assert after < before - 0.2, (before, after)
 
 
-@pytest.mark.parametrize("L,H,rows", [(8, 4, 4097), (3, 8, 100), (5, 16, 3000)])
+# one launch walks 8 / 4 / 2 layers at width 4 / 8 / 16: (9, 4), (7, 8) and (5, 16) take several, the state carried through
+# HBM; 300,000 rows: 512 blocks, rows in grid-stride order, more blocks than the gather has lanes
+@pytest.mark.parametrize("L,H,rows", [(8, 4, 4097), (3, 8, 100), (5, 16, 3000), (9, 4, 300000), (7, 8, 70001)])
 def test_split_nll_gradient_and_sgd(nfa, L, H, rows):
     """Variant A training step (src/real_nvp.py:295-306) against the oracle's float64 reverse mode."""
     from normalizing_flows_amd import training
