@@ -24,7 +24,8 @@ communicator); torch never touches the device.
 
 Prints ONE JSON line on rank 0: the contract keys for the headline (BASELINE.json
 configs[1]/[3]: 8 affine layers, banana, 2^20 rows per GPU) + `roofline` +
-`cpu_baseline`, and at N = 1 `other_configs`: configs[0], [2] and [4] timed the same way.
+`cpu_baseline`, and at N = 1 `other_configs`: configs[0], [2] and [4] and the flow of src/real_nvp.py timed the
+same way.
 """
 import argparse
 import json
@@ -40,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 # measured/spec constants: /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, spec (155 measured)
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec (6,290 measured with a float4 copy)
 BYTES_PER_EVAL = 12            # 8 B in (x[2] f32) + 4 B out (log_prob f32)
 # algorithmic (useful) FLOP per eval, SURVEY.md 8(d)
 FLOP_AFFINE_PER_LAYER = 2 * (2 * 64 + 64 * 64 + 64 * 2)           # 8,704
@@ -329,7 +331,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
     each with its useful-FLOP roofline.  Synthetic weights of the architecture, inputs resident in HBM."""
     res = []
 
-    def run(name, cfg, layers, xd, rows, steps, flop_per_eval, note, dominant=None):
+    def run(name, cfg, layers, xd, rows, steps, flop_per_eval, note, dominant=None, hbm_bound=False):
         f = flow.CouplingFlow(cfg, layers)
         lpd = flow.DeviceArray((rows,))
         step = lambda i: f.nll_enqueue(xd, rows, i % _lib.NF_NLL_SLOTS, lpd)  # noqa: E731
@@ -343,6 +345,10 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / PEAK_F32_MFMA_TFLOPS, "flop_per_eval_useful": flop_per_eval,
                                  "note": note}})
+        if hbm_bound:   # no matrix work: priced against HBM (12 algorithmic bytes per eval)
+            gbps = rows * BYTES_PER_EVAL / kern_s / 1e9
+            res[-1]["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                   "frac": gbps / PEAK_HBM_GBPS, "bytes_per_eval": BYTES_PER_EVAL, "note": note}
         if dominant is not None:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes
             traffic, src = profiled_traffic(*dominant)
             res[-1]["roofline"].update({"traffic": traffic, "traffic_unit": f"bytes of HBM per launch of {dominant[0]} "
@@ -367,6 +373,20 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
         "useful FLOP = the 37 spline parameters of the transformed dim; the kernel computes 26 of them on the MFMA "
         "and the 2 slope logits of the sample's bin on the VALU",
         dominant=("void nf::rqs2d::chain_kernel", "config_c_pmc_summary.json"))
+    del xd
+    # the flow of src/real_nvp.py (north_star's other drop-in script; not a BASELINE.json config): split halves + flip,
+    # MLP 1-4-2 with leaky relu, 8 layers, 2^24 rows -- 12 FMA per sample and layer, no matrix work
+    rng = np.random.default_rng(534)
+    layers = [[((rng.standard_normal((1, 4)) * 0.1).astype(np.float32), np.zeros(4, np.float32)),
+               ((rng.standard_normal((4, 2)) * 0.1).astype(np.float32), np.zeros(2, np.float32))] for _ in range(8)]
+    cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
+                          activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
+    xd = next(densities.get_density("energy2")(seed=2123, batch_size=1 << 24, num_batches=1, device=True))
+    run("src/real_nvp.py flow: split-halves coupling, MLP 1-4-2, 8 layers, energy2, batch=2^24", cfg, layers, xd, 1 << 24,
+        args.steps, 8 * 2 * (4 + 8),
+        "vector-issue bound (ALU 94 % busy, profiles/r02/config_a_pmc_summary.json): 21 instructions per sample "
+        "and layer; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
+        hbm_bound=True)
     del xd
     # configs[4]: MNIST shape, 6 layers, 784-D, MLP 512x3, K = 8 on [0, 1], Uniform base, 2^16 rows
     layers = [make_conditioner((784,), [512, 512, 512], 25, per_dim=True, rng=np.random.default_rng(534 + l),

@@ -104,7 +104,10 @@ if "train" in which:   # the reference's `update` step (src/real_nvp_toy_densiti
     cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
     f = flow.CouplingFlow(cfg, spec.layers)
     opt = training.adam(1e-4)
-    for lg, mode in [(7, "f32"), (12, "f32"), (20, "f32"), (20, "bf16x3")]:
+    cases = [(7, "f32"), (12, "f32"), (20, "f32"), (20, "bf16x3")]
+    if os.environ.get("NF_TRAIN_LG"):
+        cases = [(int(v), "f32") for v in os.environ["NF_TRAIN_LG"].split(",")]
+    for lg, mode in cases:
         rows = 1 << lg
         f.set_option("hidden_matmul", mode)
         xd = flow.DeviceArray.from_numpy(O.make_inputs("banana", rows))
