@@ -436,31 +436,40 @@ int launch_bwd_chain(const float* wimg, int H, int num_layers, int activation, i
 // ---------------------------------------------------------------------------
 // fixed-order float64 sum of per-block partial sums -> one scalar
 // ---------------------------------------------------------------------------
-// host_out (may be null): the handle's pinned, device-mapped result slot -- written from the kernel, so that the
-// NLL tail of a step is ONE launch and no 8-byte copy (at the reference's batch sizes the tail, not the chain
-// kernel, sets the step time: 35 -> see profiles/bench_configs.py b4k).
+// host_out (may be null): the handle's pinned, device-mapped result slot.
+// One workgroup.  Launched with 64 threads (n <= 256: every NLL step of the fused 2-D kernels): lane t adds parts
+// t, t + 64, ... in order and a shuffle tree adds the lanes -- no LDS, no barrier; with 256 threads: the same per thread,
+// then an LDS tree.  The scalar also goes to the handle's pinned host slot (system scope; the kernel's end releases it,
+// the host reads it after the event that follows the launch), so the tail of a step is one launch and no 8-byte copy.
+// Measured at BASELINE configs[0] (profiles/scratch/nll_step_b4k.py): 17.8 -> 17.4 us per step against the
+// 256-thread tree with a system fence; the step is the two kernels' launch-to-launch latency, not their work.
 __global__ __launch_bounds__(256) void sum_blocks_kernel(const double* __restrict__ part, int n,
                                                          double* __restrict__ out, double* __restrict__ host_out) {
   __shared__ double red[256];
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  double total;
+  if (blockDim.x == 64) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    total = s;
+  } else {
+    red[threadIdx.x] = s;
     __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    total = red[0];
   }
   if (threadIdx.x == 0) {
-    out[0] = red[0];
-    if (host_out != nullptr) {
-      __hip_atomic_store(host_out, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
-    }
+    out[0] = total;
+    if (host_out != nullptr) __hip_atomic_store(host_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 int launch_sum_blocks(const double* block_sums, int n, double* out_sum, hipStream_t stream, double* host_out) {
-  hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, block_sums, n, out_sum, host_out);
+  hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(n <= 256 ? 64 : 256), 0, stream, block_sums, n, out_sum, host_out);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
