@@ -384,7 +384,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
     xd = next(densities.get_density("energy2")(seed=2123, batch_size=1 << 24, num_batches=1, device=True))
     run("src/real_nvp.py flow: split-halves coupling, MLP 1-4-2, 8 layers, energy2, batch=2^24", cfg, layers, xd, 1 << 24,
         args.steps, 8 * 2 * (4 + 8),
-        "vector-issue bound (ALU 94 % busy, profiles/r02/config_a_pmc_summary.json): 21 instructions per sample "
+        "vector-issue bound (3.2 cycles per instruction per SIMD, profiles/r02/config_a_pmc_summary.json): 21 instructions per sample "
         "and layer; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
         hbm_bound=True)
     del xd

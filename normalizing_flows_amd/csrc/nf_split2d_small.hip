@@ -17,9 +17,9 @@
 //     (the two-float product that makes exp2(x * log2 e) accurate cost 5 instructions per sample and layer;
 //     prescaling rounds each weight once, the same order of error as log_scale's own float32 rounding);
 //   * a lane carries two samples (one 16-byte load); the LDS reads of a layer are shared by them.
-// Measured at 2^24 rows (profiles/bench_configs.py a): 184 us -> 96 us, vector ALU 94 % busy at 4.2 cycles per
-// instruction (profiles/r02/config_a_pmc_summary.json); per sample and layer the kernel issues 21 instructions
-// (4 x (fma, mul, max, 2 fma) + exp + 4), the operand-form table prices them at 79 cycles, the kernel spends 98.
+// Measured at 2^24 rows (profiles/bench_configs.py a): 184 us -> 84-96 us from box to box; 56,228 vector instructions
+// per SIMD in 181,800 cycles (profiles/r02/config_a_pmc_summary.json): 3.2 cycles each, the table's price for the mix --
+// per sample and layer 21 instructions (4 x (fma, mul, max, 2 fma) + exp + 4) priced at 79 cycles.
 #include "nf_internal.h"
 
 #include <math.h>
@@ -442,7 +442,8 @@ int launch_bwd_chain(const float* wimg, int H, int num_layers, int activation, i
 // then an LDS tree.  The scalar also goes to the handle's pinned host slot (system scope; the kernel's end releases it,
 // the host reads it after the event that follows the launch), so the tail of a step is one launch and no 8-byte copy.
 // Measured at BASELINE configs[0] (profiles/scratch/nll_step_b4k.py): 17.8 -> 17.4 us per step against the
-// 256-thread tree with a system fence; the step is the two kernels' launch-to-launch latency, not their work.
+// 256-thread tree with a system fence on one box, no difference on another (boxes differ by +-1 us on this step):
+// the step is the two kernels' launch-to-launch latency, not their work.
 __global__ __launch_bounds__(256) void sum_blocks_kernel(const double* __restrict__ part, int n,
                                                          double* __restrict__ out, double* __restrict__ host_out) {
   __shared__ double red[256];
