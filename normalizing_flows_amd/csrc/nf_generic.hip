@@ -218,86 +218,84 @@ __device__ __forceinline__ void gemm_fast_mainloop(const float* __restrict__ A, 
 //     [k][wn][i][{col i, col i + 32}] -- so a k step is two aligned 8-byte reads with immediate offsets instead of
 //     four ds_read_b32 behind computed addresses;
 //   * stores are laid out for the LDS's store banking (32 banks, 16-lane groups for 8-byte stores): A rows are
-//     padded to 66 floats and the rows of k >= 16 are rotated by two lanes, so that the eight lanes that hold one
-//     A row's 32 k values hit distinct banks; a thread loads W as two float2 (columns c, c+1 and c+32, c+33) and
-//     stores them as ONE 16-byte write of two whole pairs.  (A first version kept float4 W loads and scattered
+//     padded to 66 floats (a thread holds one operand pair at one k quad; sixteen lanes -- four pairs x four quads
+//     of a half tile -- hit 32 distinct banks; the rows of k >= 16 are rotated by two lanes, which did the same for
+//     the 32-wide form of the loop); a thread loads W as two float2 (columns c, c+1 and c+32, c+33) and stores them
+//     as ONE 16-byte write of two whole pairs.  (A first version kept float4 W loads and scattered
 //     them with 4-byte stores: 4-way bank conflicts, SQ_LDS_BANK_CONFLICT 338 M cycles per launch, 18 % slower
 //     than the loop it replaced.)
 // Same sums in the same order as gemm_fast_mainloop: results are bit-identical.
 constexpr int kFullARow = 66;  // floats per k row of one wm half: 32 lanes x 2 + 2 pad
 static_assert(2 * FBK * kFullARow + FBK * FBN <= kFastLdsFloats, "full-tile layout must fit the shared LDS stage");
 
+// The k tile is handled as two HALVES of 16: one LDS image (its k < 16 and k >= 16 parts are the halves), but a half
+// is fetched, stored and consumed on its own -- while the
+// waves multiply half h, each of them stores the next half into the other part as soon as its own MFMAs are issued,
+// and ONE barrier per half closes the step.  The 32-wide loop had a phase per k tile in which every wave of the
+// workgroup stored and waited (barrier, stores, barrier); timing-only builds priced that bookkeeping at ~4 % of
+// configs[4]; the half form recovers 0.55 % of it (35.85 -> 35.65 ms) with sixteen
+// prefetch registers instead of 32.  Same sums in the same order.
 __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                    int M, int N, int K, int m0, int n0, float* smem,
                                                    f32x16 (&acc)[2][2]) {
   constexpr int kAs = 2 * FBK * kFullARow;  // A tile, then the W tile
+  constexpr int HK = FBK / 2;               // 16
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  // this thread's share of a k tile.  A: rows ar + 32 e (e < 4), k quad akq.  W: rows wk + 8 e, the column pairs
-  // (wc, wc + 1) and (wc + 32, wc + 33) of half wh
-  const int ar = tid >> 3, akq = (tid & 7) * 4;
+  // this thread's share of a half: A rows (pw * 64 + pi) and (+ 32) -- one operand pair -- at k quad pq of the half;
+  // W rows wk and wk + 8 of the half, the column pairs (wc, wc + 1) and (wc + 32, wc + 33) of half wh
+  const int pq = (tid & 3) * 4, pi = (tid >> 2) & 31, pw = tid >> 7;
   const int wk = tid >> 5, wh = (tid >> 4) & 1, wc = wh * 64 + 2 * (tid & 15);
-  // A's descriptor ends with the last row's K-th float: the ragged k tile's overrun of the LAST row reads zeros
-  // instead of leaving the allocation (other rows' overrun lands in the next row and is cleared in stash)
   const long long aleft = ((long long)(M - m0 - 1) * lda + K) * 4;
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A + (size_t)m0 * lda), 0, aleft > 0x7fffffffLL ? 0x7fffffff : (int)aleft, 0x00020000);
-  // W's descriptor ends with the matrix: in a ragged last k tile the rows past K read as zeros (range check)
   const long long wleft = ((long long)K * N - n0) * 4;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(W + n0), 0, wleft > 0x7fffffffLL ? 0x7fffffff : (int)wleft, 0x00020000);
-  unsigned aoff[4], woff[4];
+  unsigned aoff[2], woff[2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    aoff[e] = ((unsigned)(min(m0 + ar + 32 * e, M - 1) - m0) * (unsigned)lda + akq) * 4u;
+  for (int e = 0; e < 2; ++e) {
+    aoff[e] = ((unsigned)(min(m0 + pw * 64 + pi + 32 * e, M - 1) - m0) * (unsigned)lda + pq) * 4u;
     woff[e] = ((unsigned)(wk + 8 * e) * (unsigned)N + wc) * 4u;
   }
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 ra[4];
-  unsigned rw[4][4];  // per W row: columns wc, wc + 32, wc + 1, wc + 33 -- the order of the 16-byte LDS store
-  auto fetch = [&](int kt) {
-    const int asoff = kt * (FBK * 4), wsoff = kt * (FBK * 4) * N;
+  u32x4 ra[2];
+  unsigned rw[2][4];
+  auto fetch = [&](int ht) {
+    const int asoff = ht * (HK * 4), wsoff = ht * (HK * 4) * N;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 2; ++e) {
       ra[e] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[e], asoff, 0);
-      // four dword loads instead of two 8-byte ones: each value lands in the register the store needs it in (packing
-      // two float2 into pair order cost four v_mov per row -- on this part VALU instructions are paid in MFMA time,
-      // loads are not)
       rw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e], wsoff, 0);
       rw[e][1] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 128u, wsoff, 0);
       rw[e][2] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 4u, wsoff, 0);
       rw[e][3] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, woff[e] + 132u, wsoff, 0);
     }
   };
-  // A: rows ar + 32 e = wm' * 64 + j * 32 + ar with e = 2 wm' + j: the thread holds both j of a pair; its four k
-  // are akq .. akq + 3, all on one side of 16: lane rotation (akq >> 4) * 2.  A pair's halves sit in the k-th register
-  // of two different 16-byte loads; ds_write2_b32 takes its two dwords from two unrelated registers (the compiler
-  // would instead fuse the stores into 8-byte ones and insert a v_mov per half: 16 per k tile).
-  const unsigned sa0 = (unsigned)(size_t)(smem + akq * kFullARow + 2 * ((ar + 2 * (akq >> 4)) & 31));  // LDS byte address
-  const unsigned sa1 = sa0 + FBK * kFullARow * 4;
+  // LDS byte addresses of the pair's first k row in half 0 / half 1 (rows of k >= 16 are rotated by two lanes)
+  const unsigned sa_h0 = (unsigned)(size_t)(smem + (pw * FBK + pq) * kFullARow + 2 * pi);
+  const unsigned sa_h1 = (unsigned)(size_t)(smem + (pw * FBK + HK + pq) * kFullARow + 2 * ((pi + 2) & 31));
   float* sw = smem + kAs + wk * FBN + wh * 64 + 4 * (tid & 15);
 #define NF_A_PAIR(base_, q_, lo_, hi_)                                                                                 \
   asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(base_), "v"(lo_), "v"(hi_), "n"((q_)*kFullARow), \
                "n"((q_)*kFullARow + 1)                                                                                 \
                : "memory")
-  const int ktail = K % FBK;  // a multiple of 4 (the fast path's alignment condition)
-  auto stash = [&](bool tail) {
-    if (tail && akq >= ktail) {
-      // last, partial k tile: this thread's k quad lies past K -- its loads fetched the next row's leading floats.
-      // W reads zeros there, but 0 * NaN of ANOTHER row must not reach this row's sums: clear them.
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ra[e] = u32x4{0u, 0u, 0u, 0u};
+  const int ktail = K % HK;  // a multiple of 4
+  auto stash = [&](int half, bool tail) {
+    if (tail && pq >= ktail) {  // this thread's k quad lies past K: it fetched another row's leading floats
+      ra[0] = u32x4{0u, 0u, 0u, 0u};
+      ra[1] = u32x4{0u, 0u, 0u, 0u};
     }
-    NF_A_PAIR(sa0, 0, ra[0][0], ra[1][0]); NF_A_PAIR(sa0, 1, ra[0][1], ra[1][1]);
-    NF_A_PAIR(sa0, 2, ra[0][2], ra[1][2]); NF_A_PAIR(sa0, 3, ra[0][3], ra[1][3]);
-    NF_A_PAIR(sa1, 0, ra[2][0], ra[3][0]); NF_A_PAIR(sa1, 1, ra[2][1], ra[3][1]);
-    NF_A_PAIR(sa1, 2, ra[2][2], ra[3][2]); NF_A_PAIR(sa1, 3, ra[2][3], ra[3][3]);
+    const unsigned sa = half ? sa_h1 : sa_h0;
+    NF_A_PAIR(sa, 0, ra[0][0], ra[1][0]); NF_A_PAIR(sa, 1, ra[0][1], ra[1][1]);
+    NF_A_PAIR(sa, 2, ra[0][2], ra[1][2]); NF_A_PAIR(sa, 3, ra[0][3], ra[1][3]);
+    float* swh = sw + half * HK * FBN;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      *reinterpret_cast<float4*>(sw + 8 * e * FBN) = make_float4(__uint_as_float(rw[e][0]), __uint_as_float(rw[e][1]),
-                                                                  __uint_as_float(rw[e][2]), __uint_as_float(rw[e][3]));
+    for (int e = 0; e < 2; ++e)
+      *reinterpret_cast<float4*>(swh + 8 * e * FBN) = make_float4(__uint_as_float(rw[e][0]), __uint_as_float(rw[e][1]),
+                                                                   __uint_as_float(rw[e][2]), __uint_as_float(rw[e][3]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores above are invisible to the compiler's counters
   };
 #undef NF_A_PAIR
@@ -308,31 +306,41 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = (K + FBK - 1) / FBK;
+  const int nh = (K + HK - 1) / HK;
   fetch(0);
-  stash(nk == 1 && ktail != 0);
+  stash(0, nh == 1 && ktail != 0);
   __syncthreads();
-  // operand reads: k = 2 s + h; rows / columns i and i + 32 of this wave's half.  Two A bases: k < 16 and k >= 16
   const float2* as_lo = reinterpret_cast<const float2*>(smem + (wm * FBK + h) * kFullARow) + i;
   const float2* as_hi = reinterpret_cast<const float2*>(smem + (wm * FBK + h) * kFullARow) + ((i + 2) & 31);
   const float2* ws = reinterpret_cast<const float2*>(smem + kAs + h * FBN) + wn * 32 + i;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) fetch(kt + 1);
-#pragma unroll
-    for (int s = 0; s < FBK / 2; ++s) {
-      const float2 a = (s < 8 ? as_lo : as_hi)[s * kFullARow];
-      const float2 b = ws[s * FBN];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();  // every wave is done with this tile
-    if (kt + 1 < nk) {
-      stash(kt + 2 == nk && ktail != 0);
-      __syncthreads();
-    }
+#define NF_HALF_STEP(as_, ws_)                                                              \
+  _Pragma("unroll") for (int s = 0; s < HK / 2; ++s) {                                       \
+    const float2 a = (as_)[s * kFullARow];                                                   \
+    const float2 b = (ws_)[s * FBN];                                                         \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);          \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);          \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);          \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);          \
   }
+  const float2* as_hi8 = as_hi + (HK / 2) * kFullARow;
+  const float2* ws8 = ws + (HK / 2) * FBN;
+  // two halves per trip so that their LDS parts are compile-time; an odd count ends with one more half
+  int ht = 0;
+  for (; ht + 2 <= nh; ht += 2) {
+    fetch(ht + 1);
+    NF_HALF_STEP(as_lo, ws)
+    stash(1, ht + 2 == nh && ktail != 0);
+    __syncthreads();
+    if (ht + 2 < nh) fetch(ht + 2);
+    NF_HALF_STEP(as_hi8, ws8)
+    if (ht + 2 < nh) stash(0, ht + 3 == nh && ktail != 0);
+    __syncthreads();
+  }
+  if (ht < nh) {
+    NF_HALF_STEP(as_lo, ws)
+    __syncthreads();
+  }
+#undef NF_HALF_STEP
 }
 
 // K, N as gemm_full_mainloop needs them?  (alignment of the bases and of lda is the fast path's own condition)
