@@ -107,6 +107,7 @@ def test_x3_option_switches_and_errors(nfa):
     spec = O.make_affine_spec(8, final_std=0.02)
     x = O.make_inputs("banana", 5000)
     f = affine_flow(nfa, spec)
+    f.set_option("hidden_matmul", "f32")   # whatever NF_HIDDEN_MATMUL made the default
     lp_f32 = f.log_prob(x)
     f.set_option("hidden_matmul", "bf16x3")
     lp_x3 = f.log_prob(x)
@@ -169,6 +170,7 @@ def test_x3_generic_affine(nfa, D, hidden, L, parity):
     f = affine_flow(nfa, spec, parity)
     assert f.kernel_name == "generic_gemm"
     x = np.random.default_rng(D * 100 + L).standard_normal((3001, D)).astype(np.float32) * 1.5
+    f.set_option("hidden_matmul", "f32")   # whatever NF_HIDDEN_MATMUL made the default
     lp32 = f.log_prob(x)
     f.set_option("hidden_matmul", "bf16x3")
     lp = f.log_prob(x)
