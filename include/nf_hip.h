@@ -276,6 +276,14 @@ int nf_timer_stop(nf_flow* flow, float* out_ms); /* synchronises on the stop eve
    count (profiles/README.md). */
 int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev);
 
+/* Diagnostic, not part of the path: one Linear of the general path, C[m, n] = act(A[m, k] W[k, n] + bias)
+   (act 0 none, 1 relu, 2 leaky_relu 0.01; the dispatch and kernels hk.nets.MLP / hk.Linear of
+   src/maf_mnist.py:34-49 run on inside a handle), on device buffers the CALLER placed: the tests put C and W
+   at the end of an allocation with sentinels behind them to pin what the kernels' buffer-descriptor range
+   checks drop (tests/test_parity_gpu.py::test_gemm_range_check_canary).  Synchronises. */
+int nf_debug_gemm(const float* a_dev, int lda, const float* w_dev, const float* bias_dev, float* c_dev, int ldc,
+                  int m, int n, int k, int act);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------- */
 /* librccl.so.1 is dlopen'ed on first use; a build box without it still loads
    libnf_hip.so.  id is an ncclUniqueId (128 bytes) made on rank 0 and handed to

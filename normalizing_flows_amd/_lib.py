@@ -111,6 +111,8 @@ PROTOTYPES = {
     "nf_timer_start": (C.c_int, [C.c_void_p]),
     "nf_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "nf_debug_read_f2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "nf_debug_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int]),
     "nf_comm_preflight": (C.c_int, []),
     "nf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "nf_comm_init_rank": (C.c_int, [_void_pp, C.c_int, C.c_int, C.c_void_p]),

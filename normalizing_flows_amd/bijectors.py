@@ -343,16 +343,20 @@ class Chain(Bijector):
                              rqs_min_knot_slope=rqs[4])
             from . import haiku_like
             frame = haiku_like.current_frame()
-            if frame is not None and frame.mode == "apply":
+            names = tuple(b.conditioner.hk_names for b in layers)
+            if frame is not None and frame.mode == "apply" and all(n is not None for n in names):
                 # built inside haiku_like's apply(params, ...): this Chain object lives for one call, the device
-                # handle is kept by the transformed function for as long as `params` keeps its values
-                slot = (cfg, tuple(b._perm for b in layers))
+                # handle is kept by the transformed function for as long as THIS chain's modules keep their values.
+                # The slot carries the chain's module names: a second model of the same architecture built by the
+                # same function reads other modules and gets its own handle.
+                slot = (cfg, tuple(b._perm for b in layers), names)
+                mods_key = frame.modules_key([n for layer in names for n in layer])
                 held = frame.owner.flow_cache.get(slot)
                 if held is None:
-                    held = (frame.params_key, CouplingFlow(cfg, [b.packed_linears() for b in layers]))
-                elif held[0] != frame.params_key:
+                    held = (mods_key, CouplingFlow(cfg, [b.packed_linears() for b in layers]))
+                elif held[0] != mods_key:
                     held[1].set_weights([b.packed_linears() for b in layers])
-                    held = (frame.params_key, held[1])
+                    held = (mods_key, held[1])
                 frame.owner.flow_cache[slot] = held
                 self._flows[base] = (key, held[1])
                 self._borrowed = True

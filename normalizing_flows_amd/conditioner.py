@@ -50,6 +50,7 @@ class MLPConditioner:
         self.activation = activation
         self.event_shape = tuple(int(s) for s in event_shape)
         self.params_per_dim = params_per_dim
+        self.hk_names: Optional[Tuple[str, ...]] = None   # haiku module names (set under haiku_like.transform)
         self.version = 0
         self.set_params(linears)
 
@@ -117,7 +118,9 @@ def make_conditioner(event_shape: Sequence[int], hidden_sizes: Sequence[int], nu
             return np.zeros((fi, fo), np.float32), np.zeros(fo, np.float32)
         shapes = list(zip(sizes, sizes[1:] + [n_out]))
         lin = haiku_like.conditioner_params(frame, shapes, hidden, final)
-        return MLPConditioner(lin, "relu", event_shape, num_bijector_params if per_dim else None)
+        cond = MLPConditioner(lin, "relu", event_shape, num_bijector_params if per_dim else None)
+        cond.hk_names = frame.last_names      # which modules of `params` this conditioner reads
+        return cond
     rng = rng if rng is not None else np.random.default_rng(42)
     lin: List[LinearParams] = []
     for fi, fo in zip(sizes[:-1], sizes[1:]):

@@ -725,7 +725,20 @@ int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
       set_error("skip_nonfinite_updates: unknown value '%s' (0, 1)", value);
       return NF_ERR_INVALID;
     }
-    f->skip_nonfinite = value[0] == '1';
+    const bool on = value[0] == '1';
+    if (on != f->skip_nonfinite && f->d_adam_bias) {
+      // Leaving the mode: the count of APPLIED steps lives on the device (it does not advance on a skipped step);
+      // it becomes the host's count, which is what the bias correction uses while the option is off, and the
+      // device copy is dropped so that switching the option on again seeds it from the host's count afresh
+      // (a stale device count would omit the steps applied in between).
+      float bias[3];
+      NF_HIP(hipStreamSynchronize(f->stream));
+      NF_HIP(hipMemcpy(bias, f->d_adam_bias, sizeof(bias), hipMemcpyDeviceToHost));
+      f->train.step = (long long)bias[2];
+      NF_HIP(hipFree(f->d_adam_bias));
+      f->d_adam_bias = nullptr;
+    }
+    f->skip_nonfinite = on;
     return NF_OK;
   }
   set_error("unknown option '%s'", name);
@@ -1013,6 +1026,17 @@ int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
 int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev) {
   if (!x_dev || !out_dev || rows < 1) { set_error("bad argument"); return NF_ERR_INVALID; }
   NF_TRY(generic::launch_debug_read_f2(x_dev, rows, out_dev, nullptr));
+  NF_HIP(hipDeviceSynchronize());
+  return NF_OK;
+}
+
+int nf_debug_gemm(const float* a_dev, int lda, const float* w_dev, const float* bias_dev, float* c_dev, int ldc,
+                  int m, int n, int k, int act) {
+  if (!a_dev || !w_dev || !bias_dev || !c_dev || m < 1 || n < 1 || k < 1 || lda < k || ldc < n || act < 0 || act > 2) {
+    set_error("bad argument");
+    return NF_ERR_INVALID;
+  }
+  NF_TRY(generic::launch_gemm(a_dev, lda, w_dev, bias_dev, c_dev, ldc, m, n, k, act, nullptr, nullptr));
   NF_HIP(hipDeviceSynchronize());
   return NF_OK;
 }

@@ -221,12 +221,10 @@ class Transformed(Distribution):
         """x, ildj = bijector.inverse_and_log_det(value); base.log_prob(x) + ildj -- one launch."""
         from . import haiku_like
         frame = haiku_like.current_frame()
-        if frame is not None and frame.mode == "init":
+        if frame is not None and frame.mode in ("init", "plan"):
             # hk.transform(...).init: every parameter exists once the model is built; nothing is evaluated
             _, batch = _flatten_rows(np.asarray(value, np.float32), self.event_shape)
             return np.zeros(batch, np.float32)
-        if frame is not None:
-            frame.check_all_used()
         flow, direction = self._lowered()
         rows, batch = _flatten_rows(value, self.event_shape)
         lib = _lib.load()
@@ -253,7 +251,7 @@ class Transformed(Distribution):
         to `bijector.forward(distribution.sample(seed=seed, sample_shape=sample_shape))`."""
         from . import haiku_like
         frame = haiku_like.current_frame()
-        if frame is not None and frame.mode == "init":
+        if frame is not None and frame.mode in ("init", "plan"):
             return np.zeros(_as_shape(sample_shape) + self.event_shape, np.float32)
         flow, direction = self._lowered()
         if direction != _lib.DIR_CHAIN_FORWARD:

@@ -19,7 +19,8 @@ those semantics for functions whose only parameterised modules are this package'
     ('w' [in, out], 'b' [out]) -- and returns that dict.  The function's result is discarded
     (haiku evaluates it; here nothing is computed: with the zero final Linear the flow is the identity anyway).
   * `apply(params, [rng,] *args)` runs the function with every `make_conditioner` call taking its parameters from
-    `params` by the same names (ValueError on a missing module or a wrong shape, as haiku raises).
+    `params` by the same names (ValueError on a missing module, a wrong shape or unused modules, as haiku raises:
+    a tree with new module names is first taken through a dry run of the function that evaluates nothing).
     The device handles the function's models lower to are kept by the transformed function and reused from call to
     call while `params` holds the same values, so a loop of `apply` calls costs one kernel launch each, not one
     handle construction and weight upload each (the reference gets the same from jax.jit's trace cache).
@@ -39,19 +40,32 @@ _FRAMES: List["_Frame"] = []
 
 class _Frame:
     def __init__(self, mode: str, params: Optional[Mapping[str, Mapping[str, np.ndarray]]], rng, owner: "Transformed"):
-        self.mode = mode                  # 'init' | 'apply'
-        self.params = params if mode == "apply" else {}
+        self.mode = mode                  # 'init' | 'plan' (apply's dry run: names and shapes only) | 'apply'
+        self.params = {} if mode == "init" else params
         self.rng = rng
         self.owner = owner
         self.layer = 0                    # conditioners created so far
-        self.params_key = None
+        self._mod_keys = {}               # module name -> content key (apply)
 
     def check_all_used(self) -> None:
-        """apply: the params dict holds exactly the coupling layers built so far (called when a model is first
-        evaluated, i.e. before anything reaches the GPU, and again when the function returns)."""
+        """apply: the params dict holds exactly the coupling layers the function built.  Called ONCE, when the
+        function has returned -- a function may build several models (and evaluate one before it builds the next),
+        so a count taken in the middle says nothing."""
         have = sum(1 for name in self.params if name.startswith("linear"))
-        if self.mode == "apply" and have != self.layer:
+        if self.mode != "init" and have != self.layer:
             raise ValueError(f"params hold {have} coupling layers, the function built {self.layer}")
+
+    def modules_key(self, names) -> tuple:
+        """Content key of the named modules only (memoised per apply call): what one chain's device weights
+        depend on."""
+        out = []
+        for name in names:
+            k = self._mod_keys.get(name)
+            if k is None:
+                mod = self.params[name]
+                k = self._mod_keys[name] = (name, _array_key(mod["w"]), _array_key(mod["b"]))
+            out.append(k)
+        return tuple(out)
 
     def next_names(self, n_hidden: int) -> Tuple[List[str], str]:
         k = self.layer
@@ -64,18 +78,19 @@ def current_frame() -> Optional[_Frame]:
     return _FRAMES[-1] if _FRAMES else None
 
 
+try:                                      # xxh3: ~10 GB/s, so the 350 MB of an MNIST-shape flow cost ~30 ms per apply
+    from xxhash import xxh3_128_digest as _digest
+except ImportError:                       # pragma: no cover - blake2b: ~1 GB/s, same guarantee
+    def _digest(buf) -> bytes:
+        return hashlib.blake2b(buf, digest_size=16).digest()
+
+
 def _array_key(a: np.ndarray) -> tuple:
-    """Identity + a content check that sees an optimiser step or an in-place edit: the full digest for small
-    arrays, a digest of a strided sample plus both ends for large ones (a 40 MB MNIST Linear is not re-hashed per
-    call; an update that touches less than one element in 4096 of a large array can slip through -- reassign the
-    array instead of editing single entries)."""
-    a = np.asarray(a)
-    flat = a.reshape(-1)
-    if flat.size <= 1 << 16:
-        sample = flat
-    else:
-        sample = np.concatenate([flat[:256], flat[::4096], flat[-256:]])
-    return (id(a), a.shape, str(a.dtype), hashlib.blake2b(np.ascontiguousarray(sample).tobytes(), digest_size=8).digest())
+    """Shape, dtype and a digest of EVERY byte: an optimiser step, a reassigned array and an in-place edit of a
+    single entry all change it (a sparse sample of large arrays, as an earlier version took, lets such an edit
+    evaluate stale device weights silently)."""
+    a = np.ascontiguousarray(a)
+    return (a.shape, str(a.dtype), _digest(memoryview(a).cast("B")))
 
 
 def params_key(params: Mapping[str, Mapping[str, np.ndarray]]) -> tuple:
@@ -88,8 +103,11 @@ class Transformed:
     def __init__(self, fn: Callable, apply_takes_rng: bool = True):
         self._fn = fn
         self._apply_takes_rng = apply_takes_rng
-        # (FlowConfig, base) -> (params_key, CouplingFlow): see Chain.lowered
+        # (FlowConfig, column orders, haiku module names of the chain) -> (content key of THOSE modules,
+        # CouplingFlow): see Chain.lowered.  Two models of one architecture built by one function have different
+        # module names, hence different slots.
         self.flow_cache: Dict[tuple, tuple] = {}
+        self._validated: Optional[frozenset] = None   # module names of the last params tree the dry run accepted
 
     def init(self, rng, *args, **kwargs) -> Dict[str, Dict[str, np.ndarray]]:
         seed = rng if isinstance(rng, (int, np.integer)) else int(np.asarray(rng).reshape(-1)[-1])
@@ -108,8 +126,16 @@ class Transformed:
             args = args[1:]
         if not isinstance(params, Mapping):
             raise ValueError("params must be the dict init() returned (haiku module name -> {'w', 'b'})")
-        frame = _Frame("apply", params, None, self)
-        frame.params_key = params_key(params)
+        names = frozenset(params)
+        if names != self._validated:
+            # dry run: the function builds its models against `params` (missing module, wrong shape and a wrong
+            # number of coupling layers raise here), evaluates nothing -- so a bad tree fails before anything
+            # reaches the GPU even when the function builds several models
+            self._run(_Frame("plan", params, None, self), args, kwargs)
+            self._validated = names
+        return self._run(_Frame("apply", params, None, self), args, kwargs)
+
+    def _run(self, frame: _Frame, args, kwargs):
         _FRAMES.append(frame)
         try:
             out = self._fn(*args, **kwargs)
@@ -128,6 +154,7 @@ def without_apply_rng(t: Transformed) -> Transformed:
     """hk.without_apply_rng: `apply(params, *args)`."""
     out = Transformed(t._fn, apply_takes_rng=False)
     out.flow_cache = t.flow_cache
+    out._validated = t._validated
     return out
 
 
@@ -149,6 +176,7 @@ def conditioner_params(frame: _Frame, shapes: List[Tuple[int, int]], make_hidden
     (init) or looked up (apply) under haiku's names."""
     hidden_names, final_name = frame.next_names(len(shapes) - 1)
     names = hidden_names + [final_name]
+    frame.last_names = tuple(names)
     out = []
     for j, (name, (fi, fo)) in enumerate(zip(names, shapes)):
         if frame.mode == "init":

@@ -218,6 +218,56 @@ def test_haiku_like_transform_init_names_and_errors():
     assert hk.params_key(params) == k0
     params["linear"]["b"][0] = 0.5
     assert hk.params_key(params) != k0
+    # ... of ONE entry of a large array too (every byte is hashed; a strided sample would miss index 12345)
+    big = {"linear": {"w": np.zeros((512, 19600), np.float32), "b": np.zeros(19600, np.float32)}}
+    k0 = hk.params_key(big)
+    big["linear"]["w"].reshape(-1)[12345] = 1e-3
+    assert hk.params_key(big) != k0
+
+
+def test_haiku_like_function_building_two_models():
+    """A transformed function may build two flows of ONE architecture (and evaluate the first before it builds the
+    second).  The tree is validated by a dry run that evaluates nothing, so a bad tree raises ValueError without a
+    GPU, the layer count is checked when the function returns and not in the middle, and each model's conditioners
+    know which modules they read (the device-handle cache is keyed on them: tests/test_full_size_gpu.py)."""
+    import normalizing_flows_amd as distrax
+    import normalizing_flows_amd.haiku_like as hk
+    seen = []
+
+    def build(event_shape, n):
+        mask = (np.arange(2) % 2).astype(bool)
+        layers = []
+        for _ in range(n):
+            def fn(p):
+                shift, log_scale = np.split(p, 2, axis=-1)
+                return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+            layers.append(distrax.MaskedCoupling(mask=mask, bijector=fn,
+                                                 conditioner=distrax.make_conditioner(event_shape, [64, 64], 2)))
+            mask = np.logical_not(mask)
+        seen.append([l.conditioner.hk_names for l in layers])
+        base = distrax.Independent(distrax.Normal(loc=np.zeros(event_shape), scale=np.ones(event_shape)), 1)
+        return distrax.Transformed(base, distrax.Inverse(distrax.Chain(layers)))
+
+    @hk.without_apply_rng
+    @hk.transform
+    def two(data):
+        a = build(data.shape[-1:], 2).log_prob(data)      # evaluated before the second model exists
+        b = build(data.shape[-1:], 2).log_prob(data)
+        return a - b
+
+    params = two.init(3, np.zeros((1, 2)))
+    assert list(params)[-1] == "linear_3" and len(params) == 12
+    assert seen[0] == [("mlp/~/linear_0", "mlp/~/linear_1", "linear"), ("mlp_1/~/linear_0", "mlp_1/~/linear_1", "linear_1")]
+    assert seen[1] == [("mlp_2/~/linear_0", "mlp_2/~/linear_1", "linear_2"), ("mlp_3/~/linear_0", "mlp_3/~/linear_1", "linear_3")]
+    x = np.zeros((4, 2), np.float32)
+    for drop in ("linear_3", "mlp_2/~/linear_1"):
+        with pytest.raises(ValueError):
+            two.apply({k: v for k, v in params.items() if k != drop}, x)
+    more = dict(params)
+    more["mlp_4/~/linear_0"], more["mlp_4/~/linear_1"], more["linear_4"] = (params[k] for k in list(params)[:3])
+    with pytest.raises(ValueError, match="5 coupling layers"):
+        two.apply(more, x)
+    assert two._validated is None            # nothing was accepted, nothing touched the GPU
 
 
 def test_lowering_recognises_reference_structures_without_a_gpu():

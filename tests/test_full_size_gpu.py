@@ -240,6 +240,64 @@ def test_reference_call_sites_unchanged_through_haiku_like(nf_lib):
     assert {id(v[1]) for v in log_prob.flow_cache.values()} == handles   # same handle, new weights
 
 
+def test_haiku_like_two_models_of_one_architecture(nf_lib):
+    """One transformed function, two flows of the same architecture on different modules of `params`: each gets its
+    own device handle and its own weights, in both orders of building and evaluating (a cache slot per
+    architecture alone would hand the second model the first one's handle without an upload)."""
+    import normalizing_flows_amd as distrax
+    import normalizing_flows_amd.haiku_like as hk
+    from normalizing_flows_amd import _lib
+    _lib.require_device()
+
+    def build(event_shape, n):
+        mask = (np.arange(2) % 2).astype(bool)
+        layers = []
+        for _ in range(n):
+            def fn(p):
+                shift, log_scale = np.split(p, 2, axis=-1)
+                return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+            layers.append(distrax.MaskedCoupling(mask=mask, bijector=fn,
+                                                 conditioner=distrax.make_conditioner(event_shape, [64, 64], 2)))
+            mask = np.logical_not(mask)
+        base = distrax.Independent(distrax.Normal(loc=np.zeros(event_shape), scale=np.ones(event_shape)), 1)
+        return distrax.Transformed(base, distrax.Inverse(distrax.Chain(layers)))
+
+    @hk.without_apply_rng
+    @hk.transform
+    def build_both_then_evaluate(data):
+        m1, m2 = build(data.shape[-1:], 4), build(data.shape[-1:], 4)
+        return np.stack([m1.log_prob(data), m2.log_prob(data)])
+
+    @hk.without_apply_rng
+    @hk.transform
+    def evaluate_between(data):
+        a = build(data.shape[-1:], 4).log_prob(data)
+        b = build(data.shape[-1:], 4).log_prob(data)
+        return np.stack([a, b])
+
+    s1 = O.make_affine_spec(4, final_std=0.03, seed=17)
+    s2 = O.make_affine_spec(4, final_std=0.03, seed=18)
+    params = _haiku_dict(s1.layers + s2.layers)
+    batch = O.make_inputs("banana", 2048, seed=5)
+    r1, r2 = O.log_prob(s1, batch), O.log_prob(s2, batch)
+    assert np.abs(r1 - r2).max() > 1e-2
+    for fn in (build_both_then_evaluate, evaluate_between):
+        for _ in range(2):                                   # second call: both handles come from the cache
+            got = fn.apply(params, batch)
+            assert_close(got[0], r1, "first model of two")
+            assert_close(got[1], r2, "second model of two")
+        assert len({id(v[1]) for v in fn.flow_cache.values()}) == 2
+    # an update of the SECOND model's parameters re-uploads that handle only
+    keys0 = {slot: v[0] for slot, v in evaluate_between.flow_cache.items()}
+    params["linear_6"]["b"] += np.float32(0.25)
+    s2.layers[2][-1] = (s2.layers[2][-1][0], params["linear_6"]["b"])
+    got = evaluate_between.apply(params, batch)
+    assert_close(got[0], r1, "first model after the second one's update")
+    assert_close(got[1], O.log_prob(s2, batch), "second model after its update")
+    changed = [slot for slot, v in evaluate_between.flow_cache.items() if v[0] != keys0[slot]]
+    assert len(changed) == 1 and changed[0][2][0][0] == "mlp_4/~/linear_0"
+
+
 # ------------------------------------------------------------------ host-side hazards
 def test_device_results_need_no_manual_synchronize(nfa):
     """Handles run on non-blocking streams; DeviceArray.to_numpy (nf_memcpy_d2h) and the handle-less device-mode

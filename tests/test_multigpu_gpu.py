@@ -29,7 +29,17 @@ def test_rccl_world2_nll_and_train_step(nfa):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29651", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0])
+    except subprocess.TimeoutExpired:
+        # a rank hung (one-sided failure inside a collective): end BOTH children, so that no process is left
+        # holding a GPU, and fail with what they printed
+        for p in procs:
+            p.kill()
+        tails = [p.communicate()[0] for p in procs]
+        pytest.fail(f"RCCL world-2 workers timed out; output so far: {tails}")
     assert all(p.returncode == 0 for p in procs), outs
     fields = [o.strip().splitlines()[-1].split() for o in outs]
     nlls = [float(f[3]) for f in fields]

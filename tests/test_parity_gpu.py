@@ -1022,3 +1022,48 @@ def test_empty_batches_on_every_path(nfa, mode):
         assert y.shape == (0, D) and ld.shape == (0,)
         one = np.full((1, D), 0.25, np.float32)        # and the smallest non-empty batch right after
         assert np.isfinite(f.log_prob(one)).all()
+
+
+# ---- what the GEMM kernels' buffer-descriptor range checks drop (general path, csrc/nf_generic.hip) -----------------
+@pytest.mark.parametrize("M,N,K,act", [(3001, 256, 36, 1), (130, 128, 44, 0), (257, 512, 784, 1), (1, 128, 32, 2)])
+def test_gemm_range_check_canary(nf_lib, M, N, K, act):
+    """gemm_fast_kernel<FULL> stores C through one buffer descriptor over rows [m0, M) with a row's offset in the
+    SCALAR offset, and reads a ragged last k tile of W / a ragged last row block of A past their ends, relying on
+    the descriptor's range check (gfx9 raw buffers: offset >= num_records - soffset is out of range).  The LLVM
+    intrinsic's documentation does not promise that for the scalar offset, so it is pinned here on the hardware:
+    C ends exactly where a sentinel region begins (a store past row M would land in it), the floats behind A and
+    behind W are NaN (a read past the end that reached a sum would poison it), one run checks both."""
+    import ctypes as C
+    from normalizing_flows_amd import _lib
+    from normalizing_flows_amd.flow import DeviceArray
+    _lib.require_device()
+    rng = np.random.default_rng(M * 7 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    pad = 1 << 16                                   # floats of NaN behind A and W: a whole tile's overrun lands inside
+    guard_rows = 256                                # sentinel rows behind C: two row blocks
+    SENT = np.float32(12345.0)
+    parts = [A.reshape(-1), np.full(pad, np.nan, np.float32), W.reshape(-1), np.full(pad, np.nan, np.float32), b,
+             np.full(pad, np.nan, np.float32), np.full(M * N, -7.0, np.float32), np.full(guard_rows * N, SENT)]
+    sizes = [((p.size + 3) // 4) * 4 for p in parts]          # keep every base 16-byte aligned
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    arena_h = np.full(offs[-1], SENT, np.float32)
+    for p, o in zip(parts, offs):
+        arena_h[o:o + p.size] = p
+    arena = DeviceArray.from_numpy(arena_h)
+    base = arena.ptr.value
+    ptr = lambda j: C.c_void_p(base + 4 * int(offs[j]))
+    _lib.check(nf_lib.nf_debug_gemm(ptr(0), K, ptr(2), ptr(4), ptr(6), N, M, N, K, act))
+    got = arena.to_numpy()
+    arena.free()
+    c = got[offs[6]:offs[6] + M * N].reshape(M, N)
+    ref = A.astype(np.float64) @ W.astype(np.float64) + b
+    ref = np.maximum(ref, 0) if act == 1 else (np.where(ref >= 0, ref, 0.01 * ref) if act == 2 else ref)
+    assert np.isfinite(c).all(), "a read past the end of A or W reached a sum"
+    assert np.abs(c - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    sentinel = got[offs[7]:offs[7] + guard_rows * N]
+    assert np.array_equal(sentinel, np.full(guard_rows * N, SENT)), "a store past row M landed behind C"
+    # nothing else of the arena moved either (inputs, NaN pads)
+    for j in (0, 2, 4):
+        assert np.array_equal(got[offs[j]:offs[j] + parts[j].size], parts[j])

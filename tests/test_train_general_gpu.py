@@ -382,6 +382,25 @@ def test_skip_nonfinite_updates(nfa, kind):
     g = make()
     g.train_step(bad, opt)
     assert not np.isfinite(_flat(g.get_weights())).all()
+    # Toggling the option keeps ONE count of applied steps: on (one skipped, one applied) -> off (one applied) ->
+    # on (one applied) must be the plain three-step run on the same good batches.  (The device-side count used
+    # under the option was once seeded a single time: switched back on it missed the steps applied meanwhile,
+    # and the host's count used while it was off had counted the skipped one.)
+    b2 = (np.random.default_rng(4).standard_normal((256, D)) * 1.5).astype(np.float32)
+    b3 = (np.random.default_rng(5).standard_normal((256, D)) * 1.5).astype(np.float32)
+    plain = make()
+    for xb in (good, b2, b3):
+        plain.train_step(xb, opt)
+    t = make()
+    t.set_option("skip_nonfinite_updates", "1")
+    t.train_step(bad, opt)
+    t.train_step(good, opt)
+    t.set_option("skip_nonfinite_updates", "0")
+    t.train_step(b2, opt)
+    t.set_option("skip_nonfinite_updates", "1")
+    t.train_step(b3, opt)
+    wp, wt = _flat(plain.get_weights()), _flat(t.get_weights())
+    assert np.abs(wt - wp).max() <= 2e-6 * max(1.0, np.abs(wp).max()), np.abs(wt - wp).max()
 
 
 @pytest.mark.parametrize("K", [21, 32])
