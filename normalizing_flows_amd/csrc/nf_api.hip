@@ -547,7 +547,7 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
     if ((e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&f->ev0)) != hipSuccess || (e = hipEventCreate(&f->ev1)) != hipSuccess ||
-        (e = hipMalloc(&f->d_block_sums, sizeof(double) * 4096 * NF_NLL_SLOTS)) != hipSuccess ||
+        (e = hipMalloc(&f->d_block_sums, sizeof(double) * kBlockSumCap * NF_NLL_SLOTS)) != hipSuccess ||
         (e = hipMalloc(&f->d_sum, sizeof(double) * NF_NLL_SLOTS)) != hipSuccess ||
         (e = hipMalloc(&f->d_reduce, sizeof(double) * NF_NLL_SLOTS)) != hipSuccess ||
         (e = hipHostMalloc(&f->h_reduce, sizeof(double) * NF_NLL_SLOTS, hipHostMallocDefault)) != hipSuccess ||
@@ -853,7 +853,7 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   if (rows_global < rows_local || rows_global < 1) { set_error("rows_global must be >= rows_local and >= 1"); return NF_ERR_INVALID; }
   NF_TRY(check_device_ptr(x_dev, "x")); NF_TRY(check_device_ptr(out_log_prob_dev, "out_log_prob"));
   int grid = 0;
-  double* sums = f->d_block_sums + (size_t)slot * 4096;
+  double* sums = f->d_block_sums + (size_t)slot * kBlockSumCap;
   // the slot's previous tail must have read its block sums before this kernel rewrites them
   if (f->tail_pending[slot]) NF_HIP(hipStreamWaitEvent(f->stream, f->ev_tail[slot], 0));
   // Small batches (the reference evaluates 128 ... 4096 rows per call): the chain kernel takes ~15 us, less than the
@@ -1177,7 +1177,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
   nf_flow::Train& t = f->train;
   const nf_flow_desc& d = f->desc;
   const int slot = 0;
-  double* sums = f->d_block_sums + (size_t)slot * 4096;
+  double* sums = f->d_block_sums + (size_t)slot * kBlockSumCap;
   if (f->tail_pending[slot]) NF_HIP(hipStreamWaitEvent(f->stream, f->ev_tail[slot], 0));
   int grid = 0;
   {

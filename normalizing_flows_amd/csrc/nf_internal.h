@@ -29,13 +29,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
   } while (0)
 
 // ---- what every chain kernel is told ------------------------------------------
+constexpr int kBlockSumCap = 16384;  // per-block float64 partial sums one NLL slot holds: every kernel's max_grid() stays below
 struct ChainIO {
   const float* x;          // [rows, D]
   const float* logdet_in;  // [rows] or null (0)
   float* y;                // [rows, D] or null
   float* logdet_out;       // [rows] or null
   float* logprob_out;      // [rows] or null: base log-density + logdet
-  double* block_sums;      // [gridDim.x] or null: per-block sum of logprob (float64)
+  double* block_sums;      // [gridDim.x <= kBlockSumCap] or null: per-block sum of logprob (float64)
   long long rows;
   int layer_begin, layer_end;  // walk layers [begin, end)
   int descending;              // 1: end-1 .. begin, 0: begin .. end-1

@@ -34,7 +34,8 @@ struct Params {
   int first_flip;  // flip of layer 0
 };
 
-// LDS image of one layer: [H] x {w0, b0, w_shift, w_logscale * log2 e}, then {b_shift, b_logscale * log2 e, 0, 0}
+// LDS image of one layer: [H] x {w0, b0, C_shift, C_logscale}, then {B_shift, B_logscale, A_shift, A_logscale}
+// (A, B, C: see layer(); everything of the log-scale output times log2 e)
 __host__ __device__ inline int lds_layer_floats(int H) { return 4 * H + 4; }
 constexpr int kMaxLdsFloats = 15 * 1024;  // 60 KB of weights per launch
 
@@ -49,29 +50,36 @@ __device__ __forceinline__ float exp_f32(float x) {
   return fmaf(e, lo * kLn2f, e);
 }
 
-constexpr float kLog2e = 1.44269504088896341f;
+constexpr double kLog2e = 1.44269504088896341;
 constexpr float kLn2 = 0.69314718055994531f;
 
-// one coupling layer on S samples: c conditions, t is transformed, ld2 = log-det in units of log 2
-template <int LEAKY, int INV, int HT, int S>
+// one coupling layer on S samples: c conditions, t is transformed, ld2 = log-det in units of log 2.
+// The activation is written act(a) = alpha a + beta |a| (relu: 1/2, 1/2; leaky_relu 0.01: 0.505, 0.495), so
+//   out_s = b_s + sum_k w_sk act(a_k),  a_k = w0_k c + b0_k
+//         = [b_s + alpha sum_k w_sk b0_k] + [alpha sum_k w_sk w0_k] c + sum_k (beta w_sk) |a_k|  =  B_s + A_s c + sum_k C_sk |a_k|
+// with A, B, C formed once per workgroup when the layer is staged (float64 sums, one rounding each): per hidden unit
+// THREE v_fma with VGPR operands (the |a| is a free source modifier) instead of fma, mul, max, fma, fma -- 14 + 3
+// vector instructions per sample and layer instead of 23, and none of the 4.2-cycle v_max (operand-form table above).
+// Not the reference's order of roundings; the same function to float32 rounding of its largest term (both signs of
+// a_k cost one rounding of |w_sk a_k| here, where the branchy form rounds w_sk act(a_k): tests hold it to the 1e-5
+// of every other kernel against float64).
+template <int INV, int HT, int S>
 __device__ __forceinline__ void layer(const float* __restrict__ w, int Hrt, const float (&c)[S], float (&t)[S],
                                       float (&ld2)[S]) {
   const int H = HT > 0 ? HT : Hrt;
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
-  const float2 bias = *reinterpret_cast<const float2*>(w + 4 * H);
+  const float4 lin = w4[H];  // {B_shift, B_logscale, A_shift, A_logscale}
   float sh[S], ls[S];
 #pragma unroll
-  for (int u = 0; u < S; ++u) { sh[u] = bias.x; ls[u] = bias.y; }
+  for (int u = 0; u < S; ++u) { sh[u] = fmaf(lin.z, c[u], lin.x); ls[u] = fmaf(lin.w, c[u], lin.y); }
 #pragma unroll 4
   for (int k = 0; k < H; ++k) {
-    const float4 wk = w4[k];
+    const float4 wk = w4[k];  // {w0, b0, C_shift, C_logscale}
 #pragma unroll
     for (int u = 0; u < S; ++u) {
-      float a = fmaf(c[u], wk.x, wk.y);
-      // jax.nn.leaky_relu, slope 0.01 < 1: max(v, 0.01 v)  (src/real_nvp.py:167)
-      a = LEAKY ? fmaxf(a, 0.01f * a) : fmaxf(a, 0.f);
-      sh[u] = fmaf(a, wk.z, sh[u]);
-      ls[u] = fmaf(a, wk.w, ls[u]);
+      const float a = fmaf(c[u], wk.x, wk.y);
+      sh[u] = fmaf(fabsf(a), wk.z, sh[u]);
+      ls[u] = fmaf(fabsf(a), wk.w, ls[u]);
     }
   }
 #pragma unroll
@@ -111,16 +119,25 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
   const int nlay = io.layer_end - io.layer_begin;
   const int SL = lds_layer_floats(H);
 
-  // stage the walked layers (global image per layer: w0[H], b0[H], w1[H][2], b1[2])
-  for (int idx = threadIdx.x; idx < nlay * SL; idx += 256) {
-    const int li = idx / SL, r = idx - li * SL;
-    const float* __restrict__ src = wimg + (size_t)(io.layer_begin + li) * layer_floats(H);
-    const int k = r >> 2, e = r & 3;
-    float v;
-    if (k < H) v = e == 0 ? src[k] : e == 1 ? src[H + k] : src[2 * H + 2 * k + (e - 2)];
-    else v = e < 2 ? src[4 * H + e] : 0.f;
-    if (e == 3 || (k == H && e == 1)) v *= kLog2e;
-    lds[idx] = v;
+  // stage the walked layers (global image per layer: w0[H], b0[H], w1[H][2], b1[2]) in the A / B / C form of layer()
+  {
+    const double alpha = LEAKY ? 0.505 : 0.5, beta = LEAKY ? 0.495 : 0.5;
+    for (int idx = threadIdx.x; idx < nlay * SL; idx += 256) {
+      const int li = idx / SL, r = idx - li * SL;
+      const float* __restrict__ src = wimg + (size_t)(io.layer_begin + li) * layer_floats(H);
+      const int k = r >> 2, e = r & 3;
+      double v;
+      if (k < H) {
+        v = e == 0 ? (double)src[k] : e == 1 ? (double)src[H + k] : beta * (double)src[2 * H + 2 * k + (e - 2)];
+      } else {
+        const int o = e & 1;  // output: 0 shift, 1 log-scale
+        double acc = 0.0;
+        for (int q = 0; q < H; ++q) acc += (double)src[2 * H + 2 * q + o] * (double)(e < 2 ? src[H + q] : src[q]);
+        v = e < 2 ? (double)src[4 * H + o] + alpha * acc : alpha * acc;
+      }
+      if ((k < H && e == 3) || (k == H && (e & 1))) v *= (double)kLog2e;
+      lds[idx] = (float)v;
+    }
   }
   __syncthreads();
 
@@ -169,16 +186,16 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
     const float* L = lds + (l - io.layer_begin) * SL;
     const int Lstep = step * SL;
     if (((l & 1) ^ p.first_flip) != 0) {  // flipped layer: dim 1 conditions, dim 0 is transformed
-      layer<LEAKY, INV, HT, S>(L, H, d1, d0, ld2);
+      layer<INV, HT, S>(L, H, d1, d0, ld2);
       L += Lstep;
       ++li;
     }
     for (; li + 1 < nlay; li += 2) {
-      layer<LEAKY, INV, HT, S>(L, H, d0, d1, ld2);
-      layer<LEAKY, INV, HT, S>(L + Lstep, H, d1, d0, ld2);
+      layer<INV, HT, S>(L, H, d0, d1, ld2);
+      layer<INV, HT, S>(L + Lstep, H, d1, d0, ld2);
       L += 2 * Lstep;
     }
-    if (li < nlay) layer<LEAKY, INV, HT, S>(L, H, d0, d1, ld2);
+    if (li < nlay) layer<INV, HT, S>(L, H, d0, d1, ld2);
 
     const long long r0 = S * g;
     const bool full = r0 + S <= rows;
@@ -257,17 +274,21 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
   p.first_flip = first_flip & 1;
   const bool leaky = activation == NF_ACT_LEAKY_RELU;
   const size_t lds_bytes = (size_t)nlay * lds_layer_floats(H) * sizeof(float);
-  // two samples per lane; four (NF_SPLIT2D_SAMPLES=4, development knob) share a layer's LDS reads between more
-  // samples but measure the same: the kernel is bound by vector issue, not by LDS or latency
-  int S = 2;
-  if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4) S = v; }
+  // four samples per lane (two 16-byte loads): a layer's LDS reads and a group's loop overhead (addresses, the
+  // float64 block sum, stores) are shared by more samples.  With the 17-instruction layer the overhead is what is
+  // left to share: 2 / 4 / 8 samples per lane measure 72.8 / 68.6-71.0 / 71.8-72.3 us at 2^24 rows
+  // (profiles/scratch/sweep_split2d.sh; NF_SPLIT2D_SAMPLES, NF_SPLIT2D_GRID are the development knobs)
+  // -- once the batch fills the chip twice over; below that two per lane keep more waves in flight
+  int S = io.rows >= (1LL << 22) ? 4 : 2;
+  if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) S = v; }
   const long long groups = (io.rows + S - 1) / S;
   long long want = (groups + 255) / 256;
   int cap = max_grid();
-  if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= 4096) cap = v; }  // block_sums holds 4096
+  if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= kBlockSumCap) cap = v; }
   const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
-  if (S == 4) launch_v<2>(p, wimg, leaky, grid, lds_bytes, stream);
+  if (S == 8) launch_v<4>(p, wimg, leaky, grid, lds_bytes, stream);
+  else if (S == 4) launch_v<2>(p, wimg, leaky, grid, lds_bytes, stream);
   else launch_v<1>(p, wimg, leaky, grid, lds_bytes, stream);
   NF_HIP(hipGetLastError());
   return NF_OK;
