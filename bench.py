@@ -25,7 +25,7 @@ communicator); torch never touches the device.
 Prints ONE JSON line on rank 0: the contract keys for the headline (BASELINE.json
 configs[1]/[3]: 8 affine layers, banana, 2^20 rows per GPU) + `roofline` +
 `cpu_baseline`, and at N = 1 `other_configs`: configs[0], [2] and [4] and the flow of src/real_nvp.py timed the
-same way.
+same way, and `next_rows`: sampling, the training step and the density generators.
 """
 import argparse
 import json
@@ -264,9 +264,10 @@ def main():
         except sharding.RanksDisagree as exc:
             coll_error = str(exc)
 
-    other = []
+    other, nxt = [], []
     if world == 1 and not args.no_other_configs and args.hidden_matmul == "f32":
         other = other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, block_stats)
+        nxt = next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block_stats)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -311,6 +312,8 @@ def main():
             out["variants"] = [variant]
         if other:
             out["other_configs"] = other
+        if nxt:
+            out["next_rows"] = nxt
         if coll_error is not None:
             out["error"] = coll_error
         if not args.no_cpu_baseline and world == 1:
@@ -400,6 +403,111 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
         max(2, min(args.steps, 5)), 6 * FLOP_MNIST_PER_LAYER,
         "whole call (4 GEMMs + spline epilogue per layer); useful FLOP = transformed pixels' columns only",
         dominant=("void nf::generic::gemm_rqs_kernel", "config_d_pmc_summary.json"))
+    return res
+
+
+def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block_stats):
+    """The callers either side of the path, measured like the configs above: sampling (f1), the
+    training step (f2) and the on-device density generators (f3).  N = 1 only; never the contract `value`."""
+    import ctypes as C
+    from normalizing_flows_amd import training
+    res = []
+    steps = args.steps
+    warm = max(2, min(args.warmup, steps))
+
+    def line(row, what, kernel, rows, wall, ev_ms, walls, unit, roofline):
+        res.append({"row": row, "what": what, "kernel": kernel, "rows": rows, "steps": steps,
+                    "value": rows * steps / wall, "unit": unit, "ms_per_step": wall * 1e3 / steps,
+                    "kernel_ms": ev_ms / steps, "block_ms": block_stats(walls, steps), "roofline": roofline})
+
+    def mfma(rows, flop, ev_ms, note):
+        tf = rows * flop / (ev_ms * 1e-3 / steps) / 1e12
+        return {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_F32_MFMA_TFLOPS, "flop_per_sample_useful": flop, "note": note}
+
+    def hbm(rows, nbytes, ev_ms, note):
+        gbps = rows * nbytes / (ev_ms * 1e-3 / steps) / 1e9
+        return {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                "bytes_per_sample": nbytes, "note": note}
+
+    rows = 1 << 20
+    aff_layers = [make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(534 + l), final_std=0.02).linears
+                  for l in range(8)]
+    aff_cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
+    rqs_layers = [make_conditioner((2,), [64, 64], 37, per_dim=True, rng=np.random.default_rng(534 + l),
+                                   final_std=0.05).linears for l in range(8)]
+    rqs_cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=8, hidden=(64, 64), rqs_bins=12,
+                              rqs_range_min=-8.0, rqs_range_max=8.0)
+
+    # f1: Transformed.sample -- Philox base draw + the generative walk (Chain.forward of the scripts' Inverse(Chain))
+    # in one call, samples left in HBM (src/real_nvp_toy_densities.py:126-136,197-203 draws 10^6)
+    for name, cfg, layers, flop in (("affine", aff_cfg, aff_layers, 8 * FLOP_AFFINE_PER_LAYER),
+                                    ("spline K=12", rqs_cfg, rqs_layers, 8 * FLOP_RQS12_PER_LAYER)):
+        f = flow.CouplingFlow(cfg, layers)
+        out = flow.DeviceArray((rows, 2))
+        step = lambda i: _lib.check(lib.nf_sample(f._h, C.c_uint64(1000 + i), rows, out.ptr, _lib.MEM_DEVICE))  # noqa: E731
+        wall, ev_ms, walls = measure(f, step, steps, warm, args.min_seconds)
+        line("f1", f"sample(2^20), 8 {name} layers: base draw + generative walk, device array out", f.kernel_name,
+             rows, wall, ev_ms, walls, "samples/s",
+             mfma(rows, flop, ev_ms, "same conditioner FLOP as log_prob; the walk is the chain's other direction"))
+        f.close()
+        out.free()
+
+    # f2: the training step (`update`: value_and_grad + optimiser, src/real_nvp_toy_densities.py:164-173) on
+    # resident batches.  Useful FLOP = 3 x forward (backward = data gradient + weight gradient); the fused affine
+    # backward stores no activations and recomputes the hidden Linear (a 4th product, not counted).
+    xd = next(densities.get_density("banana")(seed=2123, batch_size=rows, num_batches=1, device=True))
+    x128 = flow.DeviceArray.from_numpy(xd.to_numpy()[:128])
+    for name, cfg, layers, flop, opt in (("affine (headline flow), Adam", aff_cfg, aff_layers, 8 * FLOP_AFFINE_PER_LAYER,
+                                          training.adam(1e-4)),
+                                         ("spline K=12 (general backward), Adam", rqs_cfg, rqs_layers,
+                                          8 * FLOP_RQS12_PER_LAYER, training.adam(1e-4))):
+        for n, x in ((rows, xd), (128, x128)):
+            f = flow.CouplingFlow(cfg, layers)
+            step = lambda i: f.train_step(x, opt, want_nll=False)  # noqa: E731
+            wall, ev_ms, walls = measure(f, step, steps, warm, args.min_seconds if n == rows else 0.2)
+            line("f2", f"training step (forward + backward + optimiser), 8 layers {name}, batch {n}", f.kernel_name, n,
+                 wall, ev_ms, walls, "samples/s",
+                 mfma(n, 3 * flop, ev_ms, "useful FLOP = 3 x the forward's; batch 128 (the reference's) is launch-bound"))
+            f.close()
+    rng = np.random.default_rng(534)
+    a_layers = [[((rng.standard_normal((1, 4)) * 0.1).astype(np.float32), np.zeros(4, np.float32)),
+                 ((rng.standard_normal((4, 2)) * 0.1).astype(np.float32), np.zeros(2, np.float32))] for _ in range(8)]
+    a_cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
+                            activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
+    f = flow.CouplingFlow(a_cfg, a_layers)
+    opt = training.sgd(1e-3)
+    step = lambda i: f.train_step(xd, opt, want_nll=False)  # noqa: E731
+    wall, ev_ms, walls = measure(f, step, steps, warm, args.min_seconds)
+    line("f2", "training step (forward + backward + SGD), src/real_nvp.py flow (MLP 1-4-2), 8 layers, batch 2^20",
+         f.kernel_name, rows, wall, ev_ms, walls, "samples/s",
+         hbm(rows, 8 + 8 + 16 + 8, ev_ms, "forward reads x and writes z (16 B), the one backward launch reads z (8 B): "
+             "no per-layer state through HBM; vector-issue bound"))
+    f.close()
+    xd.free()
+    x128.free()
+
+    # f3: the toy-density generators on the device (src/densities/*.py restated; Philox4x32-10), 8 B written per row
+    for dens in ("banana", "gaussian_blobs"):
+        out = flow.DeviceArray((rows, 2))
+        call = lambda i: _lib.check(lib.nf_density_sample(densities.DENSITIES[dens], C.c_uint64(77 + i), rows, out.ptr,  # noqa: E731
+                                                          _lib.MEM_DEVICE))
+        for i in range(warm):
+            call(i)
+        _lib.check(lib.nf_device_synchronize())
+        walls = []
+        for b in range(10):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                call(i)
+            _lib.check(lib.nf_device_synchronize())
+            walls.append(time.perf_counter() - t0)
+        walls.sort()
+        wall = walls[len(walls) // 2]
+        line("f3", f"density generator {dens}, 2^20 rows into HBM", "density_sample_kernel", rows, wall, wall * 1e3,
+             walls, "rows/s", hbm(rows, 8, wall * 1e3, "wall-clock (the generator runs on the default stream); "
+                                  "transcendental-issue bound, 8 B written per row"))
+        out.free()
     return res
 
 
