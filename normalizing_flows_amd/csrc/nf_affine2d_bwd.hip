@@ -87,16 +87,13 @@ void build_gather_map(int cond_dim, int* map, float* scale) {
           map[cW2 + k * 64 + j] = pW2 + ((mk * 2 + mj) * 16 + r) * 64 + lane;
           scale[cW2 + k * 64 + j] = ldexpf(1.f, kReluShift);
         }
-  for (int h = 0; h < 2; ++h)
-    for (int m = 0; m < 2; ++m)
-      for (int r = 0; r < 16; ++r) {
-        const int u = unit_of(m, r, h), q = (h * 2 + m) * 16 + r;
-        map[cb2 + u] = pB2 + q;
-        map[cW3 + 2 * u + 0] = pW3 + 2 * q + 0;
-        map[cW3 + 2 * u + 1] = pW3 + 2 * q + 1;
-        map[cb1 + u] = pB1 + q;
-        map[cW1 + cond_dim * 64 + u] = pW1 + q;  // the masked input row has zero gradient
-      }
+  for (int u = 0; u < 64; ++u) {   // the small tensors leave the kernel indexed by unit (lane u of sample_sums)
+    map[cb2 + u] = pB2 + u;
+    map[cW3 + 2 * u + 0] = pW3 + 2 * u + 0;
+    map[cW3 + 2 * u + 1] = pW3 + 2 * u + 1;
+    map[cb1 + u] = pB1 + u;
+    map[cW1 + cond_dim * 64 + u] = pW1 + u;  // the masked input row has zero gradient
+  }
   map[cb3 + 0] = pB3 + 0;
   map[cb3 + 1] = pB3 + 1;
 }
@@ -137,27 +134,66 @@ __device__ __forceinline__ float half_sum(float x) {
   return x;
 }
 
-constexpr int kGT = 32 * 65;          // transposed g2 tile, padded rows
-constexpr int kWaveScratch = kGT + 32;  // + the tile's conditioning values
+// Development: -DNF_BWD_SKIP=<mask> builds a TIMING-ONLY kernel without some of its phases (wrong results, same
+// remaining instruction stream): 1 pass 1 (recompute a2), 2 the lane-local block that forms g2, 4 pass 3 (g1 = W2 g2),
+// 8 the first Linear's gradients, 16 pass 4 (dW2).  profiles/scratch/bwd_phase_timing.sh.
+#ifndef NF_BWD_SKIP
+#define NF_BWD_SKIP 0
+#endif
+
+constexpr int kWaves = 8;               // one workgroup per CU, two waves per SIMD
+constexpr int kGT = 32 * 65;            // one transposed tile [sample][unit], padded rows
+constexpr int kAop = 6 * 32;            // per-sample factors as rows [g_s | g_ls | 0 | 0 | 1 | c] (A operands below)
+constexpr int kWaveScratch = kGT + kAop;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Sum over the 32 SAMPLES of a tile of (a per-sample factor) x (a per-(unit, sample) value), for all 64 units and
+// four factors at once, on v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 blocks, K = 1; layout and cost measured in
+// profiles/microbench/mfma_f32_4x4x1_layout.hip: D[reg r][lane 4b+j] += A[lane 4b+r] * B[lane 4b+j], 8 cycles):
+// one instruction per sample with B = lane u's value X[u][sample] read from the transposed tile and A = factor
+// row (lane & 3) of that sample, so D[r][lane u] accumulates sum_i factor_r[i] X[u][i] -- over every tile the wave
+// walks, in sample order (a fixed order).  This replaces 160 lane-held accumulators (dW3, db2, db1, dW1 per unit and
+// lane, summed over lanes at the end) by 8 registers: 404 -> under 256 registers, two waves per SIMD instead of one.
+__device__ __forceinline__ void sample_sums(f32x4& D, const float* __restrict__ frow, const float* __restrict__ xt,
+                                            int lane) {
+  const float4* f4 = reinterpret_cast<const float4*>(frow);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 a = f4[q];
+    D = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, xt[(4 * q + 0) * 65 + lane], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, xt[(4 * q + 1) * 65 + lane], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, xt[(4 * q + 2) * 65 + lane], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, xt[(4 * q + 3) * 65 + lane], D, 0, 0, 0);
+  }
+}
 
 // X3: passes 1 and 3 (recompute a2; g1 = W2 g2) as six bf16 MFMAs on three-way operand splits
 // (nf_bf16x3.h); pass 4 (the weight-gradient product) and everything lane-local stay float32.
 template <bool X3>
-__global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
+  // Two LDS objects: the weight image (read-only while tiles are walked) and the waves' scratch.  In ONE array the
+  // compiler must assume that a store to the scratch may change the image: it then sinks the image reads of a
+  // select's operands into branches behind the stores (a read and a full wait per accumulator register, seen in
+  // the first build of this form) instead of fetching them ahead.
+  extern __shared__ __attribute__((aligned(16))) float lds[];                     // the image
+  __shared__ __attribute__((aligned(16))) float scratch[kWaves * kWaveScratch];  // per wave: tile + factor rows
   const int tid = threadIdx.x;
   constexpr int kImg = X3 ? kImageFloatsX3 : kImageFloats;
   {
     const float4* src = reinterpret_cast<const float4*>(p.img);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int q = tid; q < kImg / 4; q += 256) dst[q] = src[q];
+    for (int q = tid; q < kImg / 4; q += kWaves * 64) dst[q] = src[q];
   }
-  __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  float* gT = lds + kImg + wave * kWaveScratch;
-  float* cbuf = gT + kGT;
+  float* gT = scratch + wave * kWaveScratch;      // the wave's transposed tile: relu(a2), then g2, then the
+                                                  // first Linear's masked gradient, one after the other
+  float* aop = gT + kGT;
+  float* cbuf = aop + 5 * 32;                     // row 5: the tile's conditioning values
+  if (lane < 32) { aop[2 * 32 + lane] = 0.f; aop[3 * 32 + lane] = 0.f; aop[4 * 32 + lane] = 1.f; }
+  __syncthreads();
   const float* L = lds;
   const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;     // float32 form only
   const float2* a2t = reinterpret_cast<const float2*>(L + oA2T) + lane;
@@ -167,27 +203,39 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
   constexpr int OB2 = small_off<X3>(oB2), OW3 = small_off<X3>(oW3), OB3 = small_off<X3>(oB3);
   constexpr int OW1A = small_off<X3>(oW1acc), OB1A = small_off<X3>(oB1acc);
   const int hq = h * 32;  // offset of this half's [m][r] block in the accumulator-order images
+  const float* f_hv = aop + (lane & 3) * 32;        // factor rows (g_s, g_ls, 0, 0)
+  const float* f_gz = aop + ((lane & 3) + 2) * 32;  // factor rows (0, 0, 1, c)
+  float* gTw = gT + i * 65 + 4 * h;                 // this lane's 32 units of sample i: + 32 m + 8 (r >> 2) + (r & 3)
 
   f32x16 dW2[2][2];
-  float db2[2][16], dW3s[2][16], dW3l[2][16], db1[2][16], dw1[2][16];
+  f32x4 Dx = {0.f, 0.f, 0.f, 0.f};   // lane u: (dW3[u][shift], dW3[u][log_scale], db1[u], dW1[u])
+  f32x4 Dy = {0.f, 0.f, 0.f, 0.f};   // lane u: (., ., db2[u], .)
   float db3s = 0.f, db3l = 0.f;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dW2[a][0][r] = 0.f; dW2[a][1][r] = 0.f;
-      db2[a][r] = 0.f; dW3s[a][r] = 0.f; dW3l[a][r] = 0.f; db1[a][r] = 0.f; dw1[a][r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) { dW2[a][0][r] = 0.f; dW2[a][1][r] = 0.f; }
 
   const long long rows = p.rows;
   const long long tiles = (rows + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
+  // The next tile's state is requested before the current tile is walked (the first build loaded it at the top of
+  // its own iteration -- v, then behind a branch on `first` G: two exposed round trips per tile); `first`: G := v,
+  // read from the same line instead of branching.
+  const float2* __restrict__ Gsrc = p.first ? p.v : p.G;
+  const long long tstride = (long long)gridDim.x * kWaves;
+  long long tile = (long long)blockIdx.x * kWaves + wave;
+  float2 v = make_float2(0.f, 0.f), G = make_float2(0.f, 0.f);
+  if (tile < tiles && tile * 32 + i < rows) { v = p.v[tile * 32 + i]; G = Gsrc[tile * 32 + i]; }
+  // the loop is entered with no load in flight (the waits the compiler places follow the register that is read;
+  // a load still pending at the loop head would make it wait for the NEXT tile's request at the first use of v)
+  asm volatile("; tile state loaded" : "+v"(v.x), "+v"(v.y), "+v"(G.x), "+v"(G.y));
+  for (; tile < tiles; tile += tstride) {
     const long long idx = tile * 32 + i;
     const bool valid = idx < rows;
-    float2 v = make_float2(0.f, 0.f), G = make_float2(0.f, 0.f);
-    if (valid) {
-      v = p.v[idx];
-      G = p.first ? v : p.G[idx];
+    float2 v_next = make_float2(0.f, 0.f), G_next = make_float2(0.f, 0.f);
+    {
+      const long long nidx = (tile + tstride) * 32 + i;
+      if (tile + tstride < tiles && nidx < rows) { v_next = p.v[nidx]; G_next = Gsrc[nidx]; }
     }
     const float c = p.cond_dim ? v.y : v.x;
     const float tp = p.cond_dim ? v.x : v.y;
@@ -200,8 +248,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
       acc[0] = lds_f32x16(L + OB2 + hq);
       acc[1] = lds_f32x16(L + OB2 + hq + 16);
       const float4* wb = reinterpret_cast<const float4*>(w1b1) + 4 * h;  // (w1, b1) of k = 16 s + 8 h + 0..7
-      // the operand of step s+1 (52 VALU) is issued between the 12 MFMAs of step s (one wave per
-      // SIMD here: nothing else would fill the matrix pipe's shadow)
+      // the operand of step s+1 (52 VALU) is issued between the 12 MFMAs of step s
       bf16x8 B[2][3];
       auto make_B = [&](int s) {
         float hv8[8];
@@ -230,6 +277,9 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
           }
         }
       }
+    } else if ((NF_BWD_SKIP & 1) != 0) {
+      acc[0] = lds_f32x16(L + OB2 + hq);
+      acc[1] = lds_f32x16(L + OB2 + hq + 16);
     } else {
       {
         const f32x16 bias0 = lds_f32x16(L + OB2 + hq);
@@ -250,7 +300,8 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
       }
     }
 
-    // 2. (shift, log_scale), undo the affine map, gradients of the layer's two outputs
+    // 2. (shift, log_scale), undo the affine map, gradients of the layer's two outputs; relu(a2) goes to the
+    //    transposed tile for the last Linear's weight gradient
     const float2* w3 = reinterpret_cast<const float2*>(L + OW3) + hq;
     float ps = 0.f, pl = 0.f;
 #pragma unroll
@@ -261,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
         const float hv = fmaxf(acc[m][r], 0.f);
         ps = fmaf(hv, w.x, ps);
         pl = fmaf(hv, w.y, pl);
+        gTw[32 * m + 8 * (r >> 2) + (r & 3)] = hv;
       }
     const float shift = add_halves(ps) + L[OB3 + 0];
     const float ls = add_halves(pl) + L[OB3 + 1];
@@ -272,23 +324,45 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
     const float Gt = Gtp * e;
     db3s += h == 0 ? g_s : 0.f;
     db3l += h == 0 ? g_ls : 0.f;
-
-    // g2 = (W3 g_out) * [a2 > 0]; kept in `acc` as the next pass's operand and transposed into LDS
+    aop[h * 32 + i] = h ? g_ls : g_s;              // both halves hold both (identical bits)
     if (h == 0) cbuf[i] = c;
+    // dW3[u][.] += sum_i (g_s, g_ls)[i] relu(a2)[u][i]
+    sample_sums(Dx, f_hv, gT, lane);
+
+    // g2 = (W3 g_out) * [a2 > 0]; kept in `acc` as the next pass's operand and transposed into LDS (over relu(a2):
+    // a wave's LDS operations execute in order)
+    if ((NF_BWD_SKIP & 2) == 0)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float2 w = w3[m * 16 + r];
         const float a = acc[m][r];
-        const float hv = fmaxf(a, 0.f);
-        const float ga = a > 0.f ? fmaf(w.x, g_s, w.y * g_ls) : 0.f;
-        db2[m][r] += ga;
-        dW3s[m][r] = fmaf(hv, g_s, dW3s[m][r]);
-        dW3l[m][r] = fmaf(hv, g_ls, dW3l[m][r]);
+        float gfull = fmaf(w.x, g_s, w.y * g_ls);
+        // (opaque use: otherwise the select becomes a branch with W3's LDS read and a full wait inside it,
+        // once per accumulator register)
+        asm volatile("" : "+v"(gfull));
+        const float ga = a > 0.f ? gfull : 0.f;
         acc[m][r] = ga;
-        gT[i * 65 + 32 * m + 8 * (r >> 2) + 4 * h + (r & 3)] = ga;
+        gTw[32 * m + 8 * (r >> 2) + (r & 3)] = ga;
       }
+    // db2[u] += sum_i g2[u][i]
+    sample_sums(Dy, f_gz, gT, lane);
+
+    // 4. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension
+    if ((NF_BWD_SKIP & 16) == 0)
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float ci = cbuf[2 * s + h];
+      const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
+      const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
+      const float a1 = __builtin_amdgcn_fmed3f(fmaf(ci, wb1.x, wb1.y), 0.f, 1.f);
+      const float b0 = gT[(2 * s + h) * 65 + i], b1v = gT[(2 * s + h) * 65 + 32 + i];
+      dW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dW2[0][0], 0, 0, 0);
+      dW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, dW2[0][1], 0, 0, 0);
+      dW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dW2[1][0], 0, 0, 0);
+      dW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, dW2[1][1], 0, 0, 0);
+    }
 
     // 3. g1 = W2 g2 (k-steps in accumulator order)
     f32x16 g1[2];
@@ -319,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
           }
         }
       }
-    } else {
+    } else if ((NF_BWD_SKIP & 4) == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -329,7 +403,9 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
           g1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[m][r], g1[1], 0, 0, 0);
         }
     }
+    // the first Linear: gz = g1 * [w1 c + b1 > 0] -> d loss / d c, and (over g2: pass 4 has read it) the tile
     float gcm = 0.f;
+    if ((NF_BWD_SKIP & 8) == 0)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -337,62 +413,65 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(Params p) {
         const float w1a = L[OW1A + hq + m * 16 + r], b1a = L[OB1A + hq + m * 16 + r];
         const float gz = fmaf(w1a, c, b1a) > 0.f ? g1[m][r] : 0.f;
         gcm = fmaf(gz, w1a, gcm);
-        db1[m][r] += gz;
-        dw1[m][r] = fmaf(gz, c, dw1[m][r]);
+        gTw[32 * m + 8 * (r >> 2) + (r & 3)] = gz;
       }
     Gc += add_halves(gcm);
+    // (db1, dW1)[u] += sum_i (1, c[i]) gz[u][i]
+    sample_sums(Dx, f_gz, gT, lane);
 
-    // 4. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const float ci = cbuf[2 * s + h];
-      const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
-      const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
-      const float a1 = __builtin_amdgcn_fmed3f(fmaf(ci, wb1.x, wb1.y), 0.f, 1.f);
-      const float b0 = gT[(2 * s + h) * 65 + i], b1v = gT[(2 * s + h) * 65 + 32 + i];
-      dW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dW2[0][0], 0, 0, 0);
-      dW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, dW2[0][1], 0, 0, 0);
-      dW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dW2[1][0], 0, 0, 0);
-      dW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, dW2[1][1], 0, 0, 0);
-    }
-
+    const float2 v_out = p.cond_dim ? make_float2(t, c) : make_float2(c, t);
+    const float2 G_out = p.cond_dim ? make_float2(Gt, Gc) : make_float2(Gc, Gt);
+    // (before this tile's stores: the wait for the loads must not wait for the stores as well)
+    v = v_next;
+    G = G_next;
+    asm volatile("; next tile's state arrived" : "+v"(v.x), "+v"(v.y), "+v"(G.x), "+v"(G.y));
     if (h == 0 && valid) {
-      p.v[idx] = p.cond_dim ? make_float2(t, c) : make_float2(c, t);
-      p.G[idx] = p.cond_dim ? make_float2(Gt, Gc) : make_float2(Gc, Gt);
+      p.v[idx] = v_out;
+      p.G[idx] = G_out;
     }
   }
 
-  // one partial gradient per workgroup: the four waves lay theirs out in LDS (the weight image
-  // and the transpose scratch are dead by now), then they are added in wave order
-  __syncthreads();
-  float* P = lds + wave * kPartialFloats;
+  // one partial gradient per workgroup: the waves lay theirs out in the scratch (dead by now), four at a time, and
+  // they are added in wave order
+  static_assert(4 * kPartialFloats <= kWaves * kWaveScratch, "staging of four partials");
+  constexpr int kPer = (kPartialFloats + kWaves * 64 - 1) / (kWaves * 64);
+  float total[kPer];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) P[pW2 + ((a * 2 + b) * 16 + r) * 64 + lane] = dW2[a][b][r];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = hq + m * 16 + r;
-      const float s2 = half_sum(db2[m][r]), s3s = half_sum(dW3s[m][r]), s3l = half_sum(dW3l[m][r]);
-      const float s1 = half_sum(db1[m][r]), sw = half_sum(dw1[m][r]);
-      if (i == 0) {
-        P[pB2 + q] = s2;
-        P[pW3 + 2 * q + 0] = s3s;
-        P[pW3 + 2 * q + 1] = s3l;
-        P[pB1 + q] = s1;
-        P[pW1 + q] = sw;
-      }
-    }
+  for (int e = 0; e < kPer; ++e) total[e] = 0.f;
   const float t3s = half_sum(db3s), t3l = half_sum(db3l);
-  if (lane == 0) { P[pB3 + 0] = t3s; P[pB3 + 1] = t3l; P[pB3 + 2] = 0.f; P[pB3 + 3] = 0.f; }
-  __syncthreads();
+#pragma unroll
+  for (int round = 0; round < kWaves / 4; ++round) {
+    __syncthreads();
+    if ((wave >> 2) == round) {
+      float* P = scratch + (wave & 3) * kPartialFloats;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) P[pW2 + ((a * 2 + b) * 16 + r) * 64 + lane] = dW2[a][b][r];
+      P[pW3 + 2 * lane + 0] = Dx[0];
+      P[pW3 + 2 * lane + 1] = Dx[1];
+      P[pB1 + lane] = Dx[2];
+      P[pW1 + lane] = Dx[3];
+      P[pB2 + lane] = Dy[2];
+      if (lane == 0) { P[pB3 + 0] = t3s; P[pB3 + 1] = t3l; P[pB3 + 2] = 0.f; P[pB3 + 3] = 0.f; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+      const int q = tid + e * kWaves * 64;
+      if (q < kPartialFloats)
+        total[e] = (((total[e] + scratch[q]) + scratch[kPartialFloats + q]) + scratch[2 * kPartialFloats + q]) +
+                   scratch[3 * kPartialFloats + q];
+    }
+  }
   float* out = p.partials + (size_t)blockIdx.x * kPartialFloats;
-  for (int q = tid; q < kPartialFloats; q += 256)
-    out[q] = ((lds[q] + lds[kPartialFloats + q]) + lds[2 * kPartialFloats + q]) + lds[3 * kPartialFloats + q];
+#pragma unroll
+  for (int e = 0; e < kPer; ++e) {
+    const int q = tid + e * kWaves * 64;
+    if (q < kPartialFloats) out[q] = total[e];
+  }
 }
 
 // grad[e] = scale[e] / rows_global * sum over workgroups of partial[b][map[e]].  Fixed order: chunk c
@@ -472,16 +551,8 @@ int launch_build_x3_images(const float* img32, float* imgx3, int num_layers, hip
 
 int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
                  hipStream_t stream, int* out_parts, bool x3) {
-  static bool attr_set = false;
   const int image = x3 ? kImageFloatsX3 : kImageFloats;
-  const size_t lds_bytes = (size_t)std::max(image + 4 * kWaveScratch, 4 * kPartialFloats) * sizeof(float);
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  const size_t lds_bytes = (size_t)image * sizeof(float);   // + the kernel's static scratch (72.7 KB)
   Params p;
   p.img = img;
   p.v = reinterpret_cast<float2*>(v);
@@ -491,10 +562,10 @@ int launch_layer(const float* img, float* v, float* G, float* partials, long lon
   p.cond_dim = cond_dim;
   p.first = first;
   const long long tiles = (rows + 31) / 32;
-  const int grid = (int)std::min<long long>(grid_blocks(), std::max<long long>(1, (tiles + 3) / 4));
+  const int grid = (int)std::min<long long>(grid_blocks(), std::max<long long>(1, (tiles + kWaves - 1) / kWaves));
   if (out_parts) *out_parts = grid;
-  if (x3) hipLaunchKernelGGL(layer_kernel<true>, dim3(grid), dim3(256), lds_bytes, stream, p);
-  else hipLaunchKernelGGL(layer_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, p);
+  if (x3) hipLaunchKernelGGL(layer_kernel<true>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
+  else hipLaunchKernelGGL(layer_kernel<false>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
