@@ -5,7 +5,7 @@
 // No activation is stored: the flow is invertible, so the backward walk (layer 0 first, the
 // reverse of the order log_prob applies them) rebuilds each layer's input from its output while
 // it recomputes the conditioner.  One launch per layer; per 32-sample tile a wave runs three
-// 64x64 products on the f32 MFMA, all operands staying in registers except one transpose
+// 64x64 products on the f32 MFMA, all operands staying in registers except the transposes
 // through LDS:
 //   1. recompute  a2 = W2^T h1 + b2          (as the forward kernel; h1 generated from x_c)
 //   2. lane-local: (shift, log_scale), the inverse affine map, the output gradients, and
@@ -13,9 +13,15 @@
 //   3. g1 = W2 g2                            (accumulator-fed MFMA pass, k in accumulator order)
 //   4. dW2 += h1 (x) g2 summed over the tile's samples (MFMA whose K dimension is the sample
 //      index: h1 regenerated with samples on K, g2 read back transposed from LDS)
-// Bias / first / last Linear gradients accumulate lane-locally.  Every wave keeps its partial
-// gradient in registers across all its tiles and writes it once; a second kernel adds the
-// waves' partials in a fixed order, scales by 1/rows_global and scatters into the canonical
+//   5. the small tensors -- dW3, db2, db1, dW1: per unit a sum over the SAMPLES of (a per-sample factor) x (a value
+//      a lane holds for its sample) -- on v_mfma_f32_4x4x1 (sample_sums below): relu(a2), g2 and the first Linear's
+//      masked gradient pass through the wave's transposed LDS tile one after the other, lane u of the result is
+//      unit u.  The first build accumulated them per (unit, lane) in 160 registers and summed the lanes at the end:
+//      404 registers, ONE wave per SIMD, every LDS and HBM latency exposed (MFMA pipe 52 % busy, a third of the
+//      cycles idle: profiles/r03/train_b_2p20_before_*).  Now 8 registers, 229 in all, two waves per SIMD (eight
+//      per workgroup): 306 -> 259 us per layer at 2^20 rows, MFMA pipe 68 % busy.
+// Every wave keeps its partial gradient in registers across all its tiles and writes it once; a second kernel adds
+// the workgroups' partials in a fixed order, scales by 1/rows_global and scatters into the canonical
 // (nf_flow_set_weights) layout.
 #include "nf_bf16x3.h"
 #include "nf_internal.h"
@@ -141,9 +147,12 @@ __device__ __forceinline__ float half_sum(float x) {
 #define NF_BWD_SKIP 0
 #endif
 
+
 constexpr int kWaves = 8;               // one workgroup per CU, two waves per SIMD
 constexpr int kGT = 32 * 65;            // one transposed tile [sample][unit], padded rows
-constexpr int kAop = 6 * 32;            // per-sample factors as rows [g_s | g_ls | 0 | 0 | 1 | c] (A operands below)
+constexpr int kAopRow = 36;             // (rows 16 bytes apart in bank terms: the four rows a 16-byte factor read touches
+                                        // then sit on different banks -- with 32 it was a 4-way conflict, 96 cycles per tile)
+constexpr int kAop = 6 * kAopRow;       // per-sample factors as rows [g_s | g_ls | 0 | 0 | 1 | c] (A operands below)
 constexpr int kWaveScratch = kGT + kAop;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -191,8 +200,8 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
   float* gT = scratch + wave * kWaveScratch;      // the wave's transposed tile: relu(a2), then g2, then the
                                                   // first Linear's masked gradient, one after the other
   float* aop = gT + kGT;
-  float* cbuf = aop + 5 * 32;                     // row 5: the tile's conditioning values
-  if (lane < 32) { aop[2 * 32 + lane] = 0.f; aop[3 * 32 + lane] = 0.f; aop[4 * 32 + lane] = 1.f; }
+  float* cbuf = aop + 5 * kAopRow;                // row 5: the tile's conditioning values
+  if (lane < 32) { aop[2 * kAopRow + lane] = 0.f; aop[3 * kAopRow + lane] = 0.f; aop[4 * kAopRow + lane] = 1.f; }
   __syncthreads();
   const float* L = lds;
   const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;     // float32 form only
@@ -203,8 +212,8 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
   constexpr int OB2 = small_off<X3>(oB2), OW3 = small_off<X3>(oW3), OB3 = small_off<X3>(oB3);
   constexpr int OW1A = small_off<X3>(oW1acc), OB1A = small_off<X3>(oB1acc);
   const int hq = h * 32;  // offset of this half's [m][r] block in the accumulator-order images
-  const float* f_hv = aop + (lane & 3) * 32;        // factor rows (g_s, g_ls, 0, 0)
-  const float* f_gz = aop + ((lane & 3) + 2) * 32;  // factor rows (0, 0, 1, c)
+  const float* f_hv = aop + (lane & 3) * kAopRow;        // factor rows (g_s, g_ls, 0, 0)
+  const float* f_gz = aop + ((lane & 3) + 2) * kAopRow;  // factor rows (0, 0, 1, c)
   float* gTw = gT + i * 65 + 4 * h;                 // this lane's 32 units of sample i: + 32 m + 8 (r >> 2) + (r & 3)
 
   f32x16 dW2[2][2];
@@ -324,13 +333,9 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
     const float Gt = Gtp * e;
     db3s += h == 0 ? g_s : 0.f;
     db3l += h == 0 ? g_ls : 0.f;
-    aop[h * 32 + i] = h ? g_ls : g_s;              // both halves hold both (identical bits)
+    aop[h * kAopRow + i] = h ? g_ls : g_s;         // both halves hold both (identical bits)
     if (h == 0) cbuf[i] = c;
-    // dW3[u][.] += sum_i (g_s, g_ls)[i] relu(a2)[u][i]
-    sample_sums(Dx, f_hv, gT, lane);
-
-    // g2 = (W3 g_out) * [a2 > 0]; kept in `acc` as the next pass's operand and transposed into LDS (over relu(a2):
-    // a wave's LDS operations execute in order)
+    // g2 = (W3 g_out) * [a2 > 0], in `acc`: the next pass's operand
     if ((NF_BWD_SKIP & 2) == 0)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -342,27 +347,8 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
         // (opaque use: otherwise the select becomes a branch with W3's LDS read and a full wait inside it,
         // once per accumulator register)
         asm volatile("" : "+v"(gfull));
-        const float ga = a > 0.f ? gfull : 0.f;
-        acc[m][r] = ga;
-        gTw[32 * m + 8 * (r >> 2) + (r & 3)] = ga;
+        acc[m][r] = a > 0.f ? gfull : 0.f;
       }
-    // db2[u] += sum_i g2[u][i]
-    sample_sums(Dy, f_gz, gT, lane);
-
-    // 4. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension
-    if ((NF_BWD_SKIP & 16) == 0)
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const float ci = cbuf[2 * s + h];
-      const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
-      const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
-      const float a1 = __builtin_amdgcn_fmed3f(fmaf(ci, wb1.x, wb1.y), 0.f, 1.f);
-      const float b0 = gT[(2 * s + h) * 65 + i], b1v = gT[(2 * s + h) * 65 + 32 + i];
-      dW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dW2[0][0], 0, 0, 0);
-      dW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, dW2[0][1], 0, 0, 0);
-      dW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dW2[1][0], 0, 0, 0);
-      dW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, dW2[1][1], 0, 0, 0);
-    }
 
     // 3. g1 = W2 g2 (k-steps in accumulator order)
     f32x16 g1[2];
@@ -393,17 +379,31 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
           }
         }
       }
+      // dW3[u][.] += sum_i (g_s, g_ls)[i] relu(a2)[u][i]
+      sample_sums(Dx, f_hv, gT, lane);
     } else if ((NF_BWD_SKIP & 4) == 0) {
+      // ... with the last Linear's weight gradient written between its MFMAs, one sample per k step (the compiler
+      // clusters the small MFMAs after the large ones all the same; pinned in place with sched_barrier the step
+      // measured the same, 2.60 against 2.61 ms: the small MFMAs' dependent chain is not what the kernel waits for)
+      //   dW3[u][.] += sum_i (g_s, g_ls)[i] relu(a2)[u][i]
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float2 a = a2t[(m * 16 + r) * 64];
           g1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[m][r], g1[0], 0, 0, 0);
+          Dx = __builtin_amdgcn_mfma_f32_4x4x1f32(f_hv[m * 16 + r], gT[(m * 16 + r) * 65 + lane], Dx, 0, 0, 0);
           g1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[m][r], g1[1], 0, 0, 0);
         }
+    } else {
+      sample_sums(Dx, f_hv, gT, lane);
     }
-    // the first Linear: gz = g1 * [w1 c + b1 > 0] -> d loss / d c, and (over g2: pass 4 has read it) the tile
+    // g2 transposed into LDS (over relu(a2): a wave's LDS operations execute in order)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gTw[32 * m + 8 * (r >> 2) + (r & 3)] = acc[m][r];
+    // the first Linear: gz = g1 * [w1 c + b1 > 0] -> d loss / d c; gz stays in g1's registers until pass 4 has read g2
     float gcm = 0.f;
     if ((NF_BWD_SKIP & 8) == 0)
 #pragma unroll
@@ -413,10 +413,36 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
         const float w1a = L[OW1A + hq + m * 16 + r], b1a = L[OB1A + hq + m * 16 + r];
         const float gz = fmaf(w1a, c, b1a) > 0.f ? g1[m][r] : 0.f;
         gcm = fmaf(gz, w1a, gcm);
-        gTw[32 * m + 8 * (r >> 2) + (r & 3)] = gz;
+        g1[m][r] = gz;
       }
     Gc += add_halves(gcm);
-    // (db1, dW1)[u] += sum_i (1, c[i]) gz[u][i]
+
+    // 4. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension; between them
+    //    db2[u] += sum_i g2[u][i], two samples per step
+    if ((NF_BWD_SKIP & 16) == 0) {
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const float ci = cbuf[2 * s + h];
+        const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
+        const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
+        const float a1 = __builtin_amdgcn_fmed3f(fmaf(ci, wb1.x, wb1.y), 0.f, 1.f);
+        const float b0 = gT[(2 * s + h) * 65 + i], b1v = gT[(2 * s + h) * 65 + 32 + i];
+        dW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dW2[0][0], 0, 0, 0);
+        Dy = __builtin_amdgcn_mfma_f32_4x4x1f32(f_gz[2 * s], gT[(2 * s) * 65 + lane], Dy, 0, 0, 0);
+        dW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, dW2[0][1], 0, 0, 0);
+        dW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dW2[1][0], 0, 0, 0);
+        Dy = __builtin_amdgcn_mfma_f32_4x4x1f32(f_gz[2 * s + 1], gT[(2 * s + 1) * 65 + lane], Dy, 0, 0, 0);
+        dW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, dW2[1][1], 0, 0, 0);
+      }
+    } else {
+      sample_sums(Dy, f_gz, gT, lane);
+    }
+
+    // (db1, dW1)[u] += sum_i (1, c[i]) gz[u][i]  (gz over g2 in the tile)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gTw[32 * m + 8 * (r >> 2) + (r & 3)] = g1[m][r];
     sample_sums(Dx, f_gz, gT, lane);
 
     const float2 v_out = p.cond_dim ? make_float2(t, c) : make_float2(c, t);
