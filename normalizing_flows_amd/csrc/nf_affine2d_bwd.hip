@@ -4,9 +4,10 @@
 //
 // No activation is stored: the flow is invertible, so the backward walk (layer 0 first, the
 // reverse of the order log_prob applies them) rebuilds each layer's input from its output while
-// it recomputes the conditioner.  One launch per layer; per 32-sample tile a wave runs three
-// 64x64 products on the f32 MFMA, all operands staying in registers except the transposes
-// through LDS:
+// it recomputes the conditioner.  One launch for the chain (a wave walks the same tiles in every layer, the state
+// goes through HBM between layers: 16 B per sample and layer, and each layer's image through LDS); per 32-sample
+// tile and layer a wave runs three 64x64 products on the f32 MFMA, all operands staying in registers except the
+// transposes through LDS:
 //   1. recompute  a2 = W2^T h1 + b2          (as the forward kernel; h1 generated from x_c)
 //   2. lane-local: (shift, log_scale), the inverse affine map, the output gradients, and
 //      g2 = (W3 g_out) * [a2 > 0]  on the accumulator
@@ -105,14 +106,23 @@ void build_gather_map(int cond_dim, int* map, float* scale) {
 }
 
 struct Params {
-  const float* img;   // this layer's image (kImageFloats)
-  float2* v;          // [rows] state: in = the layer's output, out = its input
-  float2* G;          // [rows] d(loss_i)/d(state); read unless `first`
-  float* partials;    // [waves][kPartialFloats]
+  const float* img;       // images of the layers, layer 0 first (img_stride floats apart)
+  long long img_stride;
+  float2* v;              // [rows] state: in = z (the chain's output), out = the chain's input
+  float2* G;              // [rows] d(loss_i)/d(state); layer 0 starts from G := v (the base density's gradient)
+  float* partials;        // [num_layers][gridDim.x][kPartialFloats]
   long long rows;
-  int cond_dim;
-  int first;          // G := v (the base density's gradient) instead of reading G
+  int num_layers;
+  int parity0;            // first_mask_parity: layer l conditions on dim (parity0 + l) & 1
 };
+
+// A layer reads the state the previous layer of the SAME launch stored (same wave, other half-wave's lanes too): read
+// past the CU's vector cache, which may still hold the line from the previous layer's own read.
+__device__ __forceinline__ float2 load_state(const float2* q) {
+  const unsigned long long u =
+      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
 
 __device__ __forceinline__ float add_halves(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -180,7 +190,7 @@ __device__ __forceinline__ void sample_sums(f32x4& D, const float* __restrict__ 
 // X3: passes 1 and 3 (recompute a2; g1 = W2 g2) as six bf16 MFMAs on three-way operand splits
 // (nf_bf16x3.h); pass 4 (the weight-gradient product) and everything lane-local stay float32.
 template <bool X3>
-__global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
+__global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
   // Two LDS objects: the weight image (read-only while tiles are walked) and the waves' scratch.  In ONE array the
   // compiler must assume that a store to the scratch may change the image: it then sinks the image reads of a
   // select's operands into branches behind the stores (a read and a full wait per accumulator register, seen in
@@ -189,11 +199,6 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
   __shared__ __attribute__((aligned(16))) float scratch[kWaves * kWaveScratch];  // per wave: tile + factor rows
   const int tid = threadIdx.x;
   constexpr int kImg = X3 ? kImageFloatsX3 : kImageFloats;
-  {
-    const float4* src = reinterpret_cast<const float4*>(p.img);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int q = tid; q < kImg / 4; q += kWaves * 64) dst[q] = src[q];
-  }
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
@@ -201,8 +206,6 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
                                                   // first Linear's masked gradient, one after the other
   float* aop = gT + kGT;
   float* cbuf = aop + 5 * kAopRow;                // row 5: the tile's conditioning values
-  if (lane < 32) { aop[2 * kAopRow + lane] = 0.f; aop[3 * kAopRow + lane] = 0.f; aop[4 * kAopRow + lane] = 1.f; }
-  __syncthreads();
   const float* L = lds;
   const float2* a2 = reinterpret_cast<const float2*>(L + oA2) + lane;     // float32 form only
   const float2* a2t = reinterpret_cast<const float2*>(L + oA2T) + lane;
@@ -216,6 +219,26 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
   const float* f_gz = aop + ((lane & 3) + 2) * kAopRow;  // factor rows (0, 0, 1, c)
   float* gTw = gT + i * 65 + 4 * h;                 // this lane's 32 units of sample i: + 32 m + 8 (r >> 2) + (r & 3)
 
+  const long long rows = p.rows;
+  const long long tiles = (rows + 31) / 32;
+  const long long tstride = (long long)gridDim.x * kWaves;
+
+  // ONE launch walks the chain, layer 0 (the one log_prob applied last) first: a sample's backward depends on no other
+  // sample, a wave takes the same tiles in every layer, so a layer reads only state its own wave stored -- no grid-wide
+  // step between layers, just the workgroup's barrier around re-staging the image.  (One launch PER layer before:
+  // at the reference's batch of 128 the step was eight launch gaps long.)
+  for (int layer = 0; layer < p.num_layers; ++layer) {
+  const int cond_dim = (p.parity0 + layer) & 1;
+  const bool first = layer == 0;
+  __syncthreads();  // every wave is done with the previous layer's image and with the scratch
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.img + (size_t)layer * p.img_stride);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int q = tid; q < kImg / 4; q += kWaves * 64) dst[q] = src[q];
+  }
+  if (lane < 32) { aop[2 * kAopRow + lane] = 0.f; aop[3 * kAopRow + lane] = 0.f; aop[4 * kAopRow + lane] = 1.f; }
+  __syncthreads();
+
   f32x16 dW2[2][2];
   f32x4 Dx = {0.f, 0.f, 0.f, 0.f};   // lane u: (dW3[u][shift], dW3[u][log_scale], db1[u], dW1[u])
   f32x4 Dy = {0.f, 0.f, 0.f, 0.f};   // lane u: (., ., db2[u], .)
@@ -225,16 +248,13 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW2[a][0][r] = 0.f; dW2[a][1][r] = 0.f; }
 
-  const long long rows = p.rows;
-  const long long tiles = (rows + 31) / 32;
   // The next tile's state is requested before the current tile is walked (the first build loaded it at the top of
   // its own iteration -- v, then behind a branch on `first` G: two exposed round trips per tile); `first`: G := v,
   // read from the same line instead of branching.
-  const float2* __restrict__ Gsrc = p.first ? p.v : p.G;
-  const long long tstride = (long long)gridDim.x * kWaves;
+  const float2* Gsrc = first ? p.v : p.G;
   long long tile = (long long)blockIdx.x * kWaves + wave;
   float2 v = make_float2(0.f, 0.f), G = make_float2(0.f, 0.f);
-  if (tile < tiles && tile * 32 + i < rows) { v = p.v[tile * 32 + i]; G = Gsrc[tile * 32 + i]; }
+  if (tile < tiles && tile * 32 + i < rows) { v = load_state(p.v + tile * 32 + i); G = load_state(Gsrc + tile * 32 + i); }
   // the loop is entered with no load in flight (the waits the compiler places follow the register that is read;
   // a load still pending at the loop head would make it wait for the NEXT tile's request at the first use of v)
   asm volatile("; tile state loaded" : "+v"(v.x), "+v"(v.y), "+v"(G.x), "+v"(G.y));
@@ -244,12 +264,12 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
     float2 v_next = make_float2(0.f, 0.f), G_next = make_float2(0.f, 0.f);
     {
       const long long nidx = (tile + tstride) * 32 + i;
-      if (tile + tstride < tiles && nidx < rows) { v_next = p.v[nidx]; G_next = Gsrc[nidx]; }
+      if (tile + tstride < tiles && nidx < rows) { v_next = load_state(p.v + nidx); G_next = load_state(Gsrc + nidx); }
     }
-    const float c = p.cond_dim ? v.y : v.x;
-    const float tp = p.cond_dim ? v.x : v.y;
-    float Gc = p.cond_dim ? G.y : G.x;
-    const float Gtp = p.cond_dim ? G.x : G.y;
+    const float c = cond_dim ? v.y : v.x;
+    const float tp = cond_dim ? v.x : v.y;
+    float Gc = cond_dim ? G.y : G.x;
+    const float Gtp = cond_dim ? G.x : G.y;
 
     // 1. a2 = W2^T relu(w1 c + b1) + b2
     f32x16 acc[2];
@@ -445,8 +465,8 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
       for (int r = 0; r < 16; ++r) gTw[32 * m + 8 * (r >> 2) + (r & 3)] = g1[m][r];
     sample_sums(Dx, f_gz, gT, lane);
 
-    const float2 v_out = p.cond_dim ? make_float2(t, c) : make_float2(c, t);
-    const float2 G_out = p.cond_dim ? make_float2(Gt, Gc) : make_float2(Gc, Gt);
+    const float2 v_out = cond_dim ? make_float2(t, c) : make_float2(c, t);
+    const float2 G_out = cond_dim ? make_float2(Gt, Gc) : make_float2(Gc, Gt);
     // (before this tile's stores: the wait for the loads must not wait for the stores as well)
     v = v_next;
     G = G_next;
@@ -492,19 +512,28 @@ __global__ __launch_bounds__(kWaves * 64) void layer_kernel(Params p) {
                    scratch[3 * kPartialFloats + q];
     }
   }
-  float* out = p.partials + (size_t)blockIdx.x * kPartialFloats;
+  float* out = p.partials + ((size_t)layer * gridDim.x + blockIdx.x) * kPartialFloats;
 #pragma unroll
   for (int e = 0; e < kPer; ++e) {
     const int q = tid + e * kWaves * 64;
     if (q < kPartialFloats) out[q] = total[e];
   }
+  }  // layer
 }
 
 // grad[e] = scale[e] / rows_global * sum over workgroups of partial[b][map[e]].  Fixed order: chunk c
 // adds workgroups c, c+4, c+8, ... (Kahan), then the four chunks are added in order.
-__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ partials, int nparts,
-                                                     const int* __restrict__ map, const float* __restrict__ scale,
-                                                     float* __restrict__ grad, float inv_rows) {
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ partials_all, int nparts,
+                                                     const int* __restrict__ map0, const int* __restrict__ map1,
+                                                     const float* __restrict__ scale0, const float* __restrict__ scale1,
+                                                     int parity0, float* __restrict__ grad_all, float inv_rows) {
+  // blockIdx.y = layer: its workgroups' partials, the map of its conditioning dim, its slice of the gradient
+  const int layer = blockIdx.y;
+  const float* __restrict__ partials = partials_all + (size_t)layer * nparts * kPartialFloats;
+  const int cond = (parity0 + layer) & 1;
+  const int* __restrict__ map = cond ? map1 : map0;
+  const float* __restrict__ scale = cond ? scale1 : scale0;
+  float* __restrict__ grad = grad_all + (size_t)layer * kCanonFloats;
   __shared__ float red[4][64];
   const int el = threadIdx.x & 63, chunk = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + el;
@@ -575,31 +604,33 @@ int launch_build_x3_images(const float* img32, float* imgx3, int num_layers, hip
   return NF_OK;
 }
 
-int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream, int* out_parts, bool x3) {
+int launch_chain(const float* images, int num_layers, int first_mask_parity, float* v, float* G, float* partials,
+                 long long rows, hipStream_t stream, int* out_parts, bool x3) {
   const int image = x3 ? kImageFloatsX3 : kImageFloats;
   const size_t lds_bytes = (size_t)image * sizeof(float);   // + the kernel's static scratch (72.7 KB)
   Params p;
-  p.img = img;
+  p.img = images;
+  p.img_stride = image;
   p.v = reinterpret_cast<float2*>(v);
   p.G = reinterpret_cast<float2*>(G);
   p.partials = partials;
   p.rows = rows;
-  p.cond_dim = cond_dim;
-  p.first = first;
+  p.num_layers = num_layers;
+  p.parity0 = first_mask_parity & 1;
   const long long tiles = (rows + 31) / 32;
   const int grid = (int)std::min<long long>(grid_blocks(), std::max<long long>(1, (tiles + kWaves - 1) / kWaves));
   if (out_parts) *out_parts = grid;
-  if (x3) hipLaunchKernelGGL(layer_kernel<true>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
-  else hipLaunchKernelGGL(layer_kernel<false>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
+  if (x3) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
+  else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }
 
-int launch_gather(const float* partials, int nparts, const int* map, const float* scale, float* grad,
-                  long long rows_global, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_kernel, dim3((kCanonFloats + 63) / 64), dim3(256), 0, stream, partials, nparts, map, scale,
-                     grad, 1.0f / (float)rows_global);
+int launch_gather(const float* partials, int nparts, int num_layers, int first_mask_parity, const int* map0,
+                  const int* map1, const float* scale0, const float* scale1, float* grad, long long rows_global,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(gather_kernel, dim3((kCanonFloats + 63) / 64, num_layers), dim3(256), 0, stream, partials, nparts,
+                     map0, map1, scale0, scale1, first_mask_parity & 1, grad, 1.0f / (float)rows_global);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

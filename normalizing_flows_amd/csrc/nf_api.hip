@@ -1135,7 +1135,7 @@ static int ensure_train(nf_flow* f, long long rows) {
     NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
     NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
     NF_HIP(hipMalloc(&t.d_bwd_img, (size_t)d.num_layers * affine2d_bwd::kImageFloats * sizeof(float)));
-    NF_HIP(hipMalloc(&t.d_partials, (size_t)affine2d_bwd::grid_blocks() * 4 * affine2d_bwd::kPartialFloats * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_partials, (size_t)affine2d_bwd::grid_blocks() * d.num_layers * affine2d_bwd::kPartialFloats * sizeof(float)));
     for (int c = 0; c < 2; ++c) {
       std::vector<int> map(affine2d_bwd::kCanonFloats);
       std::vector<float> scale(affine2d_bwd::kCanonFloats);
@@ -1235,15 +1235,13 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
       t.bwd_x3_stale = false;
     }
   }
-  for (int l = 0; l < d.num_layers; ++l) {
-    const int cond = (d.first_mask_parity + l) & 1;
+  {
     int nparts = 0;
-    const float* image = bwd_x3 ? t.d_bwd_img_x3 + (size_t)l * affine2d_bwd::x3_image_floats()
-                                : t.d_bwd_img + (size_t)l * affine2d_bwd::kImageFloats;
-    NF_TRY(affine2d_bwd::launch_layer(image, t.d_state_v, t.d_state_g, t.d_partials, rows_local, cond, l == 0,
-                                      f->stream, &nparts, bwd_x3));
-    NF_TRY(affine2d_bwd::launch_gather(t.d_partials, nparts, t.d_gmap[cond], t.d_gscale[cond],
-                                       t.d_grad + (size_t)l * affine2d_bwd::kCanonFloats, rows_global, f->stream));
+    const float* images = bwd_x3 ? t.d_bwd_img_x3 : t.d_bwd_img;
+    NF_TRY(affine2d_bwd::launch_chain(images, d.num_layers, d.first_mask_parity, t.d_state_v, t.d_state_g, t.d_partials,
+                                      rows_local, f->stream, &nparts, bwd_x3));
+    NF_TRY(affine2d_bwd::launch_gather(t.d_partials, nparts, d.num_layers, d.first_mask_parity, t.d_gmap[0], t.d_gmap[1],
+                                       t.d_gscale[0], t.d_gscale[1], t.d_grad, rows_global, f->stream));
   }
   if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
   return NF_OK;

@@ -111,14 +111,17 @@ void pack_layer(const float* W1, const float* b1, const float* W2, const float* 
                 const float* b3, int cond_dim, float* image);
 void build_gather_map(int cond_dim, int* map /*[kCanonFloats]*/, float* scale);
 int grid_blocks();
-// x3: `img` is this layer's bf16x3 image (x3_image_floats() each; launch_build_x3_images makes all of
-// them from the float32 images): the two products that feed other products run as bf16x3
-int launch_layer(const float* img, float* v, float* G, float* partials, long long rows, int cond_dim, int first,
-                 hipStream_t stream, int* out_parts, bool x3 = false);
+// One launch for the whole chain (layer 0 first) + one gather for every layer's gradient.  `images`: the layers'
+// images back to back -- float32 (kImageFloats each) or, x3, bf16x3 (x3_image_floats() each; launch_build_x3_images
+// makes them from the float32 ones): the two products that feed other products then run as bf16x3.
+// partials: [num_layers][grid_blocks()][kPartialFloats].
+int launch_chain(const float* images, int num_layers, int first_mask_parity, float* v, float* G, float* partials,
+                 long long rows, hipStream_t stream, int* out_parts, bool x3 = false);
 int x3_image_floats();
 int launch_build_x3_images(const float* img32, float* imgx3, int num_layers, hipStream_t stream);
-int launch_gather(const float* partials, int nparts, const int* map, const float* scale, float* grad,
-                  long long rows_global, hipStream_t stream);
+int launch_gather(const float* partials, int nparts, int num_layers, int first_mask_parity, const int* map0,
+                  const int* map1, const float* scale0, const float* scale1, float* grad, long long rows_global,
+                  hipStream_t stream);
 }  // namespace affine2d_bwd
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 long long step, hipStream_t stream, const int* skip = nullptr,  // *skip != 0: leave everything as it is
