@@ -51,9 +51,9 @@ FLOP_MNIST_PER_LAYER = 2 * (784 * 512 + 2 * 512 * 512 + 512 * 9800)  # 11,886,59
 
 def profiled_traffic(kernel_prefix, summary_name):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this command
-    (profiles/collect_r02.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
+    (profiles/collect_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
     MI355X_MICROARCH.md prescribes and profiles/calibrate_fetch.py confirms).  None if absent."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, summary_name)
         try:
             summary = json.load(open(path))
@@ -387,8 +387,8 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
     xd = next(densities.get_density("energy2")(seed=2123, batch_size=1 << 24, num_batches=1, device=True))
     run("src/real_nvp.py flow: split-halves coupling, MLP 1-4-2, 8 layers, energy2, batch=2^24", cfg, layers, xd, 1 << 24,
         args.steps, 8 * 2 * (4 + 8),
-        "vector-issue bound (3.2 cycles per instruction per SIMD, profiles/r02/config_a_pmc_summary.json): 21 instructions per sample "
-        "and layer; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
+        "vector-issue bound: 17 instructions per sample and layer (activation as alpha a + beta |a|: three fma per hidden "
+        "unit), counters in profiles/r03/config_a_pmc_summary.json; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
         hbm_bound=True)
     del xd
     # configs[4]: MNIST shape, 6 layers, 784-D, MLP 512x3, K = 8 on [0, 1], Uniform base, 2^16 rows
