@@ -57,7 +57,10 @@ __device__ __forceinline__ void mlp_tile_product(f32x16 (&acc)[2], const float* 
 
 template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [nlin][kWFloats] then [4 waves][32 * kTileStride]
+  // two LDS objects (staged weights: read-only while tiles are walked; the waves' tiles), so that the compiler may
+  // fetch a product's weight operands ahead of the previous Linear's tile stores (nf_affine2d_bwd.hip, round 3)
+  extern __shared__ __attribute__((aligned(16))) float smem[];                        // [nlin][kWFloats]
+  __shared__ __attribute__((aligned(16))) float tiles_lds[kWaves * 32 * kTileStride];  // [waves][32 * kTileStride]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   for (int j = 0; j < a.nlin; ++j) {
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
     if (tid < 64) Wj[4096 + tid] = tid < N ? a.b[j][tid] : 0.f;
   }
   __syncthreads();
-  float* T = smem + a.nlin * kWFloats + wave * (32 * kTileStride);
+  float* T = tiles_lds + wave * (32 * kTileStride);
 
   const long long tiles = (a.rows + 31) / 32;
   for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += (long long)gridDim.x * kWaves) {
@@ -182,16 +185,17 @@ int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const 
   }
   static bool attr_set = false;
   if (!attr_set) {
+    // dynamic part: up to four staged Linears (66.5 KB) beside the static tiles (8 x 8.3 KB / 12 x 8.3 KB)
     NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_kernel<8>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kWFloats * (int)sizeof(float)));
     NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_kernel<12>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kWFloats * (int)sizeof(float)));
     attr_set = true;
   }
   // one workgroup per CU; as many waves as the LDS left beside the staged weights holds tiles for
   // (three Linears: 50 KB of weights + 12 x 8.3 KB; four: 66.5 KB + 8 x 8.3 KB)
   const int waves = nlin <= 3 ? 12 : 8;
-  const size_t lds_bytes = ((size_t)nlin * kWFloats + (size_t)waves * 32 * kTileStride) * sizeof(float);
+  const size_t lds_bytes = (size_t)nlin * kWFloats * sizeof(float);   // + the kernel's static tiles
   const long long tiles = (rows + 31) / 32;
   const long long blocks = std::max<long long>(1, std::min<long long>(256, (tiles + waves - 1) / waves));
   if (waves == 12) hipLaunchKernelGGL(mlp_small_kernel<12>, dim3((unsigned)blocks), dim3(12 * 64), lds_bytes, stream, a);

@@ -107,7 +107,11 @@ __device__ __forceinline__ void dgrad_tile(f32x16 (&o)[2], const float* TG, cons
 
 template <int NLIN>
 __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [NLIN][64 n][64 k] W^T, then [4 waves][2 tiles]
+  // Two LDS objects: the W^T images (read-only while tiles are walked) and the waves' tiles.  In one array the
+  // compiler must assume that a store to a tile may change an image and cannot fetch the images' MFMA operands ahead
+  // of the tile stores (nf_affine2d_bwd.hip, round 3).
+  extern __shared__ __attribute__((aligned(16))) float smem[];             // [NLIN][64 n][64 k] W^T
+  __shared__ __attribute__((aligned(16))) float tiles_lds[4 * 2 * kBwdTileFloats];  // [4 waves][2 tiles]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
     }
   }
   __syncthreads();
-  float* tiles_base = smem + NLIN * 4096;
+  float* tiles_base = tiles_lds;
   float* T0 = tiles_base + wave * 2 * kBwdTileFloats;
 
   f32x16 acc[NLIN][2][2];
@@ -323,17 +327,7 @@ int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, co
     a.w_rel[j] = live ? (int)(Ls[j].w_off - lo) : 0;
     a.b_rel[j] = live ? (int)(Ls[j].b_off - lo) : 0;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_bwd_kernel<2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_bwd_kernel<3>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_bwd_kernel<4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  const size_t lds_bytes = ((size_t)nlin * 4096 + (size_t)4 * 2 * kBwdTileFloats) * sizeof(float);
+  const size_t lds_bytes = (size_t)nlin * 4096 * sizeof(float);   // + the kernel's static tiles (66.6 KB)
   const long long tiles = (rows + 31) / 32;
   const int blocks = (int)std::max<long long>(1, std::min<long long>(mlp_small_bwd_max_blocks(), (tiles + 3) / 4));
   a.grad_direct = blocks == 1 ? grad + lo : nullptr;

@@ -848,7 +848,10 @@ def _flat(layers):
 
 
 @pytest.mark.parametrize("L,parity,rows,density", [(8, 1, 4096, "banana"), (3, 0, 1000, "energy2"), (1, 1, 33, "gaussian_blobs"),
-                                                   (11, 1, 5000, "energy4")])
+                                                   (11, 1, 5000, "energy4"),
+                                                   # 2188 tiles on 256 workgroups of 8 waves: some waves walk two
+                                                   # tiles (the next tile's state is requested ahead), a ragged last one
+                                                   (2, 0, 70001, "banana")])
 def test_affine_nll_gradient(nfa, L, parity, rows, density):
     """d NLL / d weights against the oracle's hand-derived float64 reverse-mode (itself checked against
     finite differences in tests/test_oracle_kat.py).  Tolerance per tensor: 2e-4 of its largest entry."""
@@ -869,6 +872,9 @@ def test_affine_nll_gradient(nfa, L, parity, rows, density):
     for l in range(L):
         masked_row = 0 if spec.masks[l][1] else 1
         assert np.all(grads[l][0][0][masked_row] == 0)
+    # fixed summation order (samples in order on the MFMA, waves, then workgroups): run-to-run identical bits
+    nll2, grads2 = f.nll_grad(x)
+    assert nll2 == nll and np.array_equal(_flat(grads2), _flat(grads))
 
 
 def test_affine_adam_training_steps(nfa):
