@@ -330,7 +330,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             layers4 = [make_conditioner((2,), [64, 64], 2, rng=np.random.default_rng(534 + l), final_std=0.02).linears
                        for l in range(4)]
-            out["cpu_baseline"] = cpu_baseline(layers, layers4, args.density)
+            try:
+                out["cpu_baseline"] = cpu_baseline(layers, layers4, args.density)
+            except Exception as exc:  # noqa: BLE001 -- e.g. the oracle's C library missing on the box
+                out.setdefault("side_errors", []).append(f"cpu_baseline: {type(exc).__name__}: {exc}")
         print(json.dumps(out))
 
     if dist is not None:
