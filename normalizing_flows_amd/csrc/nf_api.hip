@@ -152,7 +152,7 @@ struct nf_flow {
     float* d_bwd_img = nullptr;     // [L][affine2d_bwd::kImageFloats]
     float* d_bwd_img_x3 = nullptr;  // [L][x3_image_floats()], built from d_bwd_img when the handle's mode is bf16x3
     bool bwd_x3_stale = true;
-    float* d_partials = nullptr;    // [waves][kPartialFloats]
+    float* d_partials = nullptr;    // [layers][workgroups][kPartialFloats] (split flow: its own layout)
     int* d_gmap[2] = {nullptr, nullptr};      // gather maps for cond_dim 0 / 1
     float* d_gscale[2] = {nullptr, nullptr};
     int *d_fsrc = nullptr, *d_bsrc = nullptr;                // image <- canon maps (forward / backward images)

@@ -99,10 +99,10 @@ constexpr int oB2 = oB1acc + 64;
 constexpr int oW3 = oB2 + 64;       // [2 half][2 mtile][16 reg][2]
 constexpr int oB3 = oW3 + 128;
 constexpr int kImageFloats = oB3 + 8;  // 8648
-// one wave's partial gradient (floats)
+// one workgroup's partial gradient of one layer (floats)
 constexpr int pW2 = 0;              // [2 mk][2 mj][16 reg][64 lane]  (still carries 2^-64)
-constexpr int pB2 = 4096;           // [2 half][2 mtile][16 reg]
-constexpr int pW3 = pB2 + 64;       // [...][2]
+constexpr int pB2 = 4096;           // [64 units]: the small tensors leave the kernel indexed by unit
+constexpr int pW3 = pB2 + 64;       // [64 units][2]
 constexpr int pB1 = pW3 + 128;
 constexpr int pW1 = pB1 + 64;
 constexpr int pB3 = pW1 + 64;
