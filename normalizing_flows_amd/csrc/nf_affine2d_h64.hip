@@ -266,6 +266,146 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 4 ? WAVES / 4 : 1) void chain_
   }
 }
 
+// ------------------------------------------------------------------ few tiles: two waves per tile
+// Up to 512 tiles (16,384 rows: the reference trains and evaluates at batch 128) every tile can have TWO SIMDs.  A tile's
+// latency is its dependent chain of 64 MFMAs per layer, 32 per row block of W2: wave 2q of a workgroup takes row block 0
+// of tile q, wave 2q+1 row block 1, each its own SIMD -- 32 MFMAs per layer in parallel.  The last Linear's dot products
+// stay ONE fma chain in the order of chain_kernel (row block 0's 16 registers, then row block 1's): the first wave hands
+// its partial sums to the second through LDS, the second finishes them and hands (shift, log_scale) back -- two workgroup
+// barriers per layer, and the same bits as every other geometry of this kernel (a row's result does not depend on the
+// batch it arrives in).  Measured (profiles/small_batch.py, 8 layers): see DESIGN 3.1.
+template <int WAVES, int INV>
+__global__ __launch_bounds__(WAVES * 64, 1) void chain_kernel_msplit(Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float2 hand[WAVES / 2][64];  // partial sums one way, (shift, log_scale) the other
+  const ChainIO& io = p.io;
+  const int tid = threadIdx.x;
+  const int nlay = io.layer_end - io.layer_begin;
+  constexpr int NTHREADS = WAVES * 64;
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wimg + (size_t)io.layer_begin * kLayerFloats);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = nlay * (kLayerFloats / 4);
+    for (int q = tid; q < n4; q += NTHREADS) dst[q] = src[q];
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave >> 1, mblk = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const long long rows = io.rows;
+  const long long tiles = (rows + 31) / 32;
+  const float2* __restrict__ xin = reinterpret_cast<const float2*>(io.x);
+  const long long tstride = (long long)gridDim.x * (WAVES / 2);
+  const long long first = (long long)blockIdx.x * (WAVES / 2);
+  // every wave of a workgroup walks the same number of rounds (the barriers are the workgroup's)
+  const long long rounds = first < tiles ? (tiles - first + tstride - 1) / tstride : 0;
+  double wave_sum = 0.0;
+
+  for (long long round = 0; round < rounds; ++round) {
+    const long long g = first + round * tstride + pair;  // may lie past the last tile: computes on zeros, stores nothing
+    const int l_first = io.descending ? io.layer_end - 1 : io.layer_begin;
+    const int c_first = (p.first_mask_parity + l_first) & 1;
+    const long long idx = g * 32 + i;
+    const bool valid = g < tiles && idx < rows;
+    float2 v = make_float2(0.f, 0.f);
+    if (valid) v = xin[idx];
+    float xc = c_first ? v.y : v.x;
+    float xt = c_first ? v.x : v.y;
+    float ld = (io.logdet_in != nullptr && valid) ? io.logdet_in[idx] : 0.f;
+
+    for (int li = 0; li < nlay; ++li) {
+      const int lrel = io.descending ? nlay - 1 - li : li;
+      const float* L = lds + lrel * kLayerFloats;
+      const float* a2 = L + kA2 + lane * 2 + mblk;                           // + s*128: this wave's row block of W2
+      const float2* w1b1 = reinterpret_cast<const float2*>(L + kW1B1) + h;  // + 2*s
+      f32x16 acc = lds_f32x16(L + kB2 + (h * 2 + mblk) * 16);
+#pragma unroll 8
+      for (int s = 0; s < 32; ++s) {
+        const float2 wb = w1b1[2 * s];
+        const float b = __builtin_amdgcn_fmed3f(fmaf(xc, wb.x, wb.y), 0.f, 1.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s * 128], b, acc, 0, 0, 0);
+      }
+      // the last Linear's chain: row block 0's registers, then row block 1's (the order of chain_kernel)
+      const float4* w3 = reinterpret_cast<const float4*>(L + kW3 + h * 64) + mblk * 8;
+      float ps = 0.f, pl = 0.f;
+      if (mblk == 1) {
+        __syncthreads();                       // A: the first wave's partial sums are in `hand`
+        const float2 part = hand[pair][lane];
+        ps = part.x;
+        pl = part.y;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float4 w = w3[r / 2];
+        const float v0 = fmaxf(acc[r], 0.f);
+        const float v1 = fmaxf(acc[r + 1], 0.f);
+        ps = fmaf(v0, w.x, ps);
+        pl = fmaf(v0, w.y, pl);
+        ps = fmaf(v1, w.z, ps);
+        pl = fmaf(v1, w.w, pl);
+      }
+      float shift, ls;
+      if (mblk == 0) {
+        hand[pair][lane] = make_float2(ps, pl);
+        __syncthreads();                       // A
+        __syncthreads();                       // B: (shift, log_scale) are back
+        const float2 res = hand[pair][lane];
+        shift = res.x;
+        ls = res.y;
+      } else {
+        shift = add_halves(ps) + L[kB3 + 0];
+        ls = add_halves(pl) + L[kB3 + 1];
+        hand[pair][lane] = make_float2(shift, ls);
+        __syncthreads();                       // B
+      }
+      float nt;
+      if (INV) {
+        nt = (xt - shift) * exp_f32(-ls);
+        ld -= ls;
+      } else {
+        nt = fmaf(xt, exp_f32(ls), shift);
+        ld += ls;
+      }
+      xt = xc;
+      xc = nt;
+    }
+
+    const int c_last = (c_first + nlay) & 1;
+    const float v0 = c_last ? xt : xc;
+    const float v1 = c_last ? xc : xt;
+    float lp = ld;
+    if (io.add_base) {
+      if (io.base == NF_BASE_STD_NORMAL) {
+        lp += -0.5f * (v0 * v0 + v1 * v1) - 1.8378770664093453f;
+      } else {
+        const bool inside = v0 >= 0.f && v0 <= 1.f && v1 >= 0.f && v1 <= 1.f;
+        if (!inside) lp = -INFINITY;
+      }
+    }
+    if (mblk == 0 && h == 0 && valid) {
+      if (io.y) reinterpret_cast<float2*>(io.y)[idx] = make_float2(v0, v1);
+      if (io.logdet_out) io.logdet_out[idx] = ld;
+      if (io.logprob_out) io.logprob_out[idx] = lp;
+      wave_sum += (double)lp;
+    }
+  }
+
+  if (io.block_sums) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_sum += __shfl_down(wave_sum, off);
+    __syncthreads();  // all waves are done with the weight images
+    double* red = reinterpret_cast<double*>(lds);
+    if (lane == 0) red[wave] = wave_sum;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; w += 2) s += red[w];
+      io.block_sums[blockIdx.x] = s;
+    }
+  }
+}
+
 int max_grid() { return 256; }
 
 template <int T, int WAVES, int INV>
@@ -311,6 +451,33 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
   p.first_mask_parity = first_mask_parity;
   const size_t lds_bytes = (size_t)nlay * kLayerFloats * sizeof(float) + 128;
   const int cap = grid_cap > 0 && grid_cap < max_grid() ? grid_cap : max_grid();
+  // few tiles: two waves (two SIMDs) per tile -- one tile per workgroup up to `cap` tiles, two up to 2 * cap
+  // (NF_AFFINE2D_NO_MSPLIT=1: the one-wave-per-tile geometries below, for A/B)
+  {
+    const long long tiles = (io.rows + 31) / 32;
+    if (tiles >= 1 && tiles <= 2LL * cap && getenv("NF_AFFINE2D_TUNE") == nullptr && getenv("NF_AFFINE2D_NO_MSPLIT") == nullptr) {
+      const int per = tiles <= cap ? 1 : 2;
+      const int grid = (int)((tiles + per - 1) / per);
+      if (out_grid) *out_grid = grid;
+      static bool attr_ms = false;
+      if (!attr_ms) {
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_ms = true;
+      }
+      if (per == 1) {
+        if (io.inverse_op) hipLaunchKernelGGL((chain_kernel_msplit<2, 1>), dim3(grid), dim3(128), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((chain_kernel_msplit<2, 0>), dim3(grid), dim3(128), lds_bytes, stream, p);
+      } else {
+        if (io.inverse_op) hipLaunchKernelGGL((chain_kernel_msplit<4, 1>), dim3(grid), dim3(256), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((chain_kernel_msplit<4, 0>), dim3(grid), dim3(256), lds_bytes, stream, p);
+      }
+      NF_HIP(hipGetLastError());
+      return NF_OK;
+    }
+  }
   int waves = tune.waves == 8 ? 8 : (tune.waves == 4 ? 4 : 16);
   // small batches: waves of one workgroup share the CU's four MFMA pipes, so fewer waves per
   // workgroup and more workgroups finish sooner (4096 rows: 35 us -> see profiles/bench_configs.py)
