@@ -400,7 +400,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
                           activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
     xd = next(densities.get_density("energy2")(seed=2123, batch_size=1 << 24, num_batches=1, device=True))
     run("src/real_nvp.py flow: split-halves coupling, MLP 1-4-2, 8 layers, energy2, batch=2^24", cfg, layers, xd, 1 << 24,
-        args.steps, 8 * 2 * (4 + 8),
+        max(args.steps, 200), 8 * 2 * (4 + 8),   # 75 us per step: 20 of them would be as long as the block's own bracket
         "vector-issue bound: 17 instructions per sample and layer (activation as alpha a + beta |a|: three fma per hidden "
         "unit), counters in profiles/r03/config_a_pmc_summary.json; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
         hbm_bound=True)

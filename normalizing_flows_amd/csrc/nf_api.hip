@@ -860,7 +860,12 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   // two event records and two stream waits that move the tail to the side stream cost the host -- the step was
   // API-bound at 36 us.  There the sum kernel follows on the same stream and writes the scalar into the pinned ring:
   // two launches, nothing else.
-  if (f->comm == nullptr && f->h_ring_dev != nullptr && rows_local > 0 && rows_local <= kInlineTailRows) {
+  // (the split flow of src/real_nvp.py has no matrix work: its kernel is 8 us at 2^20 rows, so the same holds up to
+  // 2^21 -- 13.2 against 15.8 us per step at 2^20; from 2^22 on the side stream wins again:
+  // profiles/scratch/nll_step_split2d.py)
+  long long inline_rows = f->path == PATH_SPLIT2D_SMALL ? (1LL << 21) : kInlineTailRows;
+  if (const char* e = getenv("NF_INLINE_TAIL_LG")) inline_rows = 1LL << atoi(e);   // development
+  if (f->comm == nullptr && f->h_ring_dev != nullptr && rows_local > 0 && rows_local <= inline_rows) {
     NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, sums, &grid));
     NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->stream, f->h_ring_dev + slot));
     f->tail_pending[slot] = false;
