@@ -99,3 +99,40 @@ def test_trained_nll_against_the_entropy_of_the_data(nfa, kind, density, steps, 
     assert nll <= H + gap, f"{kind} on {density}: NLL {nll:.4f} after {steps} steps, entropy {H:.4f}"
     assert nll < nll0 - 0.05 or nll0 <= H + gap
     print(f"{kind:6s} {density:15s} H = {H:.4f}  NLL before {nll0:.4f}  after {steps} steps {nll:.4f}")
+
+
+@pytest.mark.parametrize("kind,density,steps,lr", [("affine", "banana", 600, 2e-3), ("rqs", "gaussian_blobs", 600, 2e-3),
+                                                   ("split", "banana", 1500, 5e-3)])
+def test_density_integrates_to_one(nfa, kind, density, steps, lr):
+    """exp(log_prob) of a trained (strongly non-identity) flow integrates to 1 over the plane: midpoint rule on a
+    4096 x 4096 grid over [-12, 12]^2 evaluated by the GPU kernels in one 2^24-row call and summed in float64 on the
+    host, PLUS the mass outside the box measured with 2^20 draws of `sample` (the generative walk: the other direction
+    of the same chain).  A property of any correct change of variables -- no restatement of the flow involved; a log-det
+    off by a factor, a missing term or a density walk that is not the inverse of the generative one moves the sum by far
+    more than the 1e-3 allowed.  Far in the tails a trained affine flow's float32 exp(log_scale) overflows (log_prob
+    -inf or NaN there, as in any float32 evaluation): such points count as zero density, and the sum still closes."""
+    from normalizing_flows_amd import _lib, densities, training
+    f = _make(nfa, kind, seed=11)
+    f.set_option("skip_nonfinite_updates", "1")
+    opt = training.adam(lr) if kind != "split" else training.sgd(lr)
+    for xb in densities.get_density(density)(seed=2123, batch_size=4096, num_batches=steps, device=True):
+        f.train_step(xb, opt, want_nll=False)
+        xb.free()
+    n, L = 4096, 12.0
+    dx = 2.0 * L / n
+    axis = (-L + (np.arange(n) + 0.5) * dx).astype(np.float32)
+    g = np.empty((n, n, 2), np.float32)
+    g[:, :, 0] = axis[None, :]
+    g[:, :, 1] = axis[:, None]
+    lp = f.log_prob(g.reshape(-1, 2)).astype(np.float64)
+    assert not (lp == np.inf).any()
+    p = np.exp(np.where(np.isfinite(lp), lp, -np.inf))
+    inside = float(p.sum()) * dx * dx
+    s = nfa.DeviceArray((1 << 20, 2))
+    _lib.check(_lib.load().nf_sample(f._h, 123, 1 << 20, s.ptr, _lib.MEM_DEVICE))
+    f.synchronize()
+    outside = float((np.abs(s.to_numpy()).max(-1) > L).mean())
+    # far from the identity: the density's peak is not the base density's 1 / 2 pi = 0.159
+    assert abs(float(p.max()) - 1.0 / (2.0 * math.pi)) > 0.01, p.max()
+    assert abs(inside + outside - 1.0) <= 1e-3, f"{kind}: {inside:.6f} inside the box + {outside:.2e} outside"
+    print(f"{kind:6s} on {density}: integral over the box {inside:.6f} + sampled mass outside {outside:.2e} = {inside + outside:.6f}")
