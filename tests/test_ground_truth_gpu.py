@@ -179,3 +179,53 @@ def test_mnist_shape_density_integrates_to_one_over_the_unit_cube(nfa):
     assert abs(est - 1.0) <= 4.0 * err + 1e-3, (est, err)
     # Jensen: E log q <= log E q = 0, strictly for a non-identity flow
     assert lp.mean() < -0.01
+
+
+@pytest.mark.parametrize("kind", ["affine", "rqs", "split"])
+def test_gradient_against_finite_differences_of_the_gpu_nll(nfa, kind):
+    """d NLL / d weight from the backward kernels against central differences of the NLL the FORWARD kernels report
+    (float64 reduction over 2^16 rows, weights moved by +-h through nf_flow_set_weights): the two halves of the training
+    step checked against each other on the GPU, no restatement in between.  Twelve weights per flow, drawn over all
+    layers and tensors; float32 log_prob noise averaged over 2^16 rows leaves the difference quotient good to ~1e-4."""
+    from normalizing_flows_amd import densities
+    f = _make(nfa, kind, seed=21)
+    layers = f.get_weights()
+    rng = np.random.default_rng(99)
+    # move away from the reference's zero-initialised last Linear: a generic point
+    layers = [[(W + (rng.standard_normal(W.shape) * 0.05).astype(np.float32), b + (rng.standard_normal(b.shape) * 0.05).astype(np.float32))
+               for W, b in layer] for layer in layers]
+    f.set_weights(layers)
+    x = next(densities.get_density("banana")(seed=5, batch_size=1 << 16, num_batches=1, device=True))
+    nll, grads = f.nll_grad(x)
+    assert np.isfinite(nll)
+    checked = 0
+    worst = 0.0
+    for _ in range(12):
+        l = int(rng.integers(len(layers)))
+        j = int(rng.integers(len(layers[l])))
+        which = int(rng.integers(2))
+        t = layers[l][j][which]
+        g = grads[l][j][which]
+        # the largest-gradient entry of a random row/column neighbourhood: a structural zero says nothing
+        flat = np.abs(g).reshape(-1)
+        cand = rng.integers(flat.size, size=16)
+        e = int(cand[np.argmax(flat[cand])])
+        if flat[e] == 0.0:
+            continue
+        h = 2e-3
+        vals = []
+        for sgn in (+1.0, -1.0):
+            moved = [[(W.copy(), b.copy()) for W, b in layer] for layer in layers]
+            moved[l][j][which].reshape(-1)[e] = t.reshape(-1)[e] + np.float32(sgn * h)
+            f.set_weights(moved)
+            step = float(moved[l][j][which].reshape(-1)[e]) - float(t.reshape(-1)[e])   # what float32 made of +-h
+            vals.append((f.nll(x), step))
+        fd = (vals[0][0] - vals[1][0]) / (vals[0][1] - vals[1][1])
+        got = float(g.reshape(-1)[e])
+        err = abs(fd - got)
+        worst = max(worst, err / max(abs(got), 1e-3))
+        assert err <= 2e-2 * abs(got) + 2e-4, (kind, l, j, which, e, fd, got)
+        checked += 1
+    f.set_weights(layers)
+    assert checked >= 8
+    print(f"{kind}: {checked} weights, worst |fd - grad| / max(|grad|, 1e-3) = {worst:.2e}")
