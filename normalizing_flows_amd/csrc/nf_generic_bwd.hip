@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void gather_weights_kernel(const float* __rest
     w[q] = index[q] >= 0 ? canon[index[q]] : 0.f;
 }
 
+__global__ __launch_bounds__(256) void scatter_weights_kernel(const float* __restrict__ w, const int* __restrict__ index,
+                                                              float* __restrict__ canon, long long total) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
+    if (index[q] >= 0) canon[index[q]] = w[q];
+}
+
 __global__ __launch_bounds__(256) void scatter_grad_kernel(const float* __restrict__ g, const int* __restrict__ index,
                                                            float* __restrict__ canon_grad, long long total) {
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256)
@@ -502,10 +508,24 @@ int Plan::refresh_from_canonical(const float* d_canon, hipStream_t stream) {
   Backward& b = bwd;
   hipLaunchKernelGGL(gather_weights_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream,
                      d_canon, b.d_canon_index, d_weights, (long long)b.n_weights);
+  NF_HIP(hipGetLastError());
+  return refresh_after_step(stream);
+}
+
+int Plan::refresh_after_step(hipStream_t stream) {
+  Backward& b = bwd;
   hipLaunchKernelGGL(transpose_all_kernel, dim3(b.transpose_blocks, (unsigned)linears.size()), dim3(256), 0, stream,
                      d_weights, b.d_wT, static_cast<const TransposeJob*>(b.d_jobs));
   NF_HIP(hipGetLastError());
   k5_stale = true;  // the training walk does not use the fused last Linear: re-laid when an evaluation asks for it
+  return NF_OK;
+}
+
+int Plan::scatter_weights_to_canonical(float* d_canon, hipStream_t stream) {
+  Backward& b = bwd;
+  hipLaunchKernelGGL(scatter_weights_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream,
+                     d_weights, b.d_canon_index, d_canon, (long long)b.n_weights);
+  NF_HIP(hipGetLastError());
   return NF_OK;
 }
 
@@ -565,7 +585,7 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
     b.scratch_rows = want;
   }
   NF_HIP(hipMemsetAsync(b.d_grad, 0, b.n_weights * sizeof(float), stream));
-  NF_HIP(hipMemsetAsync(grad_canon, 0, weight_count * sizeof(float), stream));
+  if (grad_canon) NF_HIP(hipMemsetAsync(grad_canon, 0, weight_count * sizeof(float), stream));
   hipLaunchKernelGGL(base_grad_kernel, dim3(grid_for(rows * D)), dim3(256), 0, stream, v, g, rows * D, d.base, inv_n);
 
   const long long R = b.scratch_rows;
@@ -634,8 +654,9 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       NF_HIP(hipGetLastError());
     }
   }
-  hipLaunchKernelGGL(scatter_grad_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream, b.d_grad,
-                     b.d_canon_index, grad_canon, (long long)b.n_weights);
+  if (grad_canon)
+    hipLaunchKernelGGL(scatter_grad_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream, b.d_grad,
+                       b.d_canon_index, grad_canon, (long long)b.n_weights);
   NF_HIP(hipGetLastError());
   return NF_OK;
 }

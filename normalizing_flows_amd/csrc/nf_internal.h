@@ -125,8 +125,10 @@ int launch_gather(const float* partials, int nparts, int num_layers, int first_m
 }  // namespace affine2d_bwd
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 long long step, hipStream_t stream, const int* skip = nullptr,  // *skip != 0: leave everything as it is
-                float* dev_bias = nullptr);  // [3] with skip: device-side step count and bias corrections (applied steps only)
-int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip = nullptr);
+                float* dev_bias = nullptr,  // [3] with skip: device-side step count and bias corrections (applied steps only)
+                const int* live = nullptr);  // [n] or null: entries with live[e] < 0 are left alone (plan layout)
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip = nullptr,
+               const int* live = nullptr);
 int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream);  // *flag = any NaN / inf in g
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
                   hipStream_t stream);
@@ -251,9 +253,15 @@ struct Plan {
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
   int prepare_backward();            // after build(): index map, transposes, buffers
-  int refresh_from_canonical(const float* d_canon, hipStream_t stream);  // after an optimiser step
+  int refresh_from_canonical(const float* d_canon, hipStream_t stream);  // new canonical weights -> d_weights (+ below)
+  // The optimiser works on d_weights itself (the plan's layout: masked rows and pruned columns are not there to be
+  // updated -- their gradient is a structural zero in the reference too): after a step only the transposes follow ...
+  int refresh_after_step(hipStream_t stream);
+  // ... and the canonical vector is brought up to date when somebody asks for the weights
+  int scatter_weights_to_canonical(float* d_canon, hipStream_t stream);
   // z [rows, D]: the chain's output of a walk() recorded with record_tape.  g [rows, D]: scratch.
-  // grad_canon [weight_count]: receives d(NLL)/d(packed weights), NLL = -mean over rows_global.
+  // The gradient d(NLL)/d(d_weights), NLL = -mean over rows_global, is left in bwd.d_grad (plan layout); grad_canon
+  // [weight_count], if not null, also receives it in the packed (canonical) layout.
   int backward(const float* z, float* g, long long rows, long long rows_global, float* grad_canon,
                size_t weight_count, hipStream_t stream);
   int build(const nf_flow_desc& d, const float* packed);
