@@ -400,7 +400,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
                           activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
     xd = next(densities.get_density("energy2")(seed=2123, batch_size=1 << 24, num_batches=1, device=True))
     run("src/real_nvp.py flow: split-halves coupling, MLP 1-4-2, 8 layers, energy2, batch=2^24", cfg, layers, xd, 1 << 24,
-        max(args.steps, 200), 8 * 2 * (4 + 8),   # 75 us per step: 20 of them would be as long as the block's own bracket
+        args.steps, 8 * 2 * (4 + 8),
         "vector-issue bound: 17 instructions per sample and layer (activation as alpha a + beta |a|: three fma per hidden "
         "unit), counters in profiles/r03/config_a_pmc_summary.json; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
         hbm_bound=True)
@@ -500,6 +500,27 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     f.close()
     xd.free()
     x128.free()
+
+    # f2, image shape: the reference's own MNIST training configuration (src/maf_mnist.py:34-89,159-168: 8 layers, 784-D,
+    # MLP 512 x 3, K = 8, batch 128) -- weight-bound: every step reads the 46 M live weights twice, writes their gradient
+    # and runs Adam over them (10 floats of traffic per live weight)
+    mn_layers = [make_conditioner((784,), [512, 512, 512], 25, per_dim=True, rng=np.random.default_rng(534 + l),
+                                  final_std=0.01).linears for l in range(8)]
+    mn_cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=784, num_layers=8, hidden=(512, 512, 512), rqs_bins=8,
+                             rqs_range_min=0.0, rqs_range_max=1.0, base=_lib.BASE_UNIFORM01)
+    f = flow.CouplingFlow(mn_cfg, mn_layers)
+    del mn_layers
+    xm = flow.DeviceArray.from_numpy((np.random.default_rng(1).integers(0, 256, (128, 784)) / 256.0).astype(np.float32))
+    opt = training.adam(1e-4)
+    step = lambda i: f.train_step(xm, opt, want_nll=False)  # noqa: E731
+    wall, ev_ms, walls = measure(f, step, steps, warm, 0.2)
+    live = 8 * (392 * 512 + 512 + 2 * (512 * 512 + 512) + 512 * 9800 + 9800)
+    line("f2", "training step (forward + backward + Adam), MNIST shape of src/maf_mnist.py: 8 layers, 784-D, batch 128",
+         f.kernel_name, 128, wall, ev_ms, walls, "samples/s",
+         hbm(1, live * 4 * 10, ev_ms, "per step: the live weights read by the forward and the backward walk, their gradient "
+             "written, Adam's 7 floats per weight; launch-bound (65 split-K GEMMs with their reductions)"))
+    f.close()
+    xm.free()
 
     # f3: the toy-density generators on the device (src/densities/*.py restated; Philox4x32-10), 8 B written per row
     for dens in ("banana", "gaussian_blobs"):
