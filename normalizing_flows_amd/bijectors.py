@@ -169,6 +169,9 @@ class _LayerSignature:
         return (self.kind, self.event_shape, self.hidden, self.activation, self.rqs)
 
 
+_SIGNATURES: dict = {}   # MaskedCoupling._signature_cache_key() -> (_LayerSignature, column order)
+
+
 class MaskedCoupling(Bijector):
     """distrax.MaskedCoupling (src/real_nvp_toy_densities.py:90-98).
 
@@ -211,9 +214,53 @@ class MaskedCoupling(Bijector):
     conditioner = property(lambda self: self._conditioner)
 
     # -- what does bijector_fn build? -------------------------------------------
+    def _signature_cache_key(self):
+        """haiku_like's apply re-runs the model-building function on every call, so every call meets new
+        MaskedCoupling objects around a NEW closure of the same `bijector_fn` source.  What the probe below finds
+        depends on that function's code, on what it closes over and on the layer's shapes only: cached per
+        (code object, closure contents, defaults, mask, conditioner shape) -- 8 probes of 2 calls each were 300 us of
+        a 445 us `log_prob.apply(params, batch)` at the reference's batch of 128.  None: not cacheable."""
+        fn = self._bijector_fn
+        code = getattr(fn, "__code__", None)
+        if code is None:
+            return None
+        parts = [code]
+        try:
+            for cell in (fn.__closure__ or ()):
+                v = cell.cell_contents
+                if isinstance(v, (int, float, str, bool, bytes, type(None), tuple)):
+                    parts.append(("v", v))
+                elif isinstance(v, (np.ndarray, list, dict, set)):
+                    return None                       # mutable content: probe every time
+                else:
+                    parts.append(("o", id(v)))        # modules, classes, functions: identity
+            parts.append(("d", fn.__defaults__, tuple(sorted((fn.__kwdefaults__ or {}).items()))))
+            c = self._conditioner
+            parts.append((self._mask.shape, self._mask.tobytes(), c.in_size, c.out_size, c.params_per_dim,
+                          c.hidden_sizes, c.activation))
+            key = tuple(parts)
+            hash(key)
+            return key
+        except (TypeError, ValueError):
+            return None
+
     def signature(self) -> _LayerSignature:
         if self._sig is not None:
             return self._sig
+        key = self._signature_cache_key()
+        if key is not None:
+            hit = _SIGNATURES.get(key)
+            if hit is not None:
+                self._sig, self._perm = hit
+                return self._sig
+        sig = self._probe_signature()
+        if key is not None:
+            if len(_SIGNATURES) > 256:
+                _SIGNATURES.clear()
+            _SIGNATURES[key] = (sig, self._perm)
+        return sig
+
+    def _probe_signature(self) -> _LayerSignature:
         cond = self._conditioner
         flat = self._mask.reshape(-1)
         D = flat.size

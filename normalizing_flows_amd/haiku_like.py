@@ -90,7 +90,7 @@ def _array_key(a: np.ndarray) -> tuple:
     single entry all change it (a sparse sample of large arrays, as an earlier version took, lets such an edit
     evaluate stale device weights silently)."""
     a = np.ascontiguousarray(a)
-    return (a.shape, str(a.dtype), _digest(memoryview(a).cast("B")))
+    return (a.shape, a.dtype.num, _digest(memoryview(a).cast("B")))   # (str(dtype) alone cost 3 us per array)
 
 
 def params_key(params: Mapping[str, Mapping[str, np.ndarray]]) -> tuple:

@@ -270,6 +270,48 @@ def test_haiku_like_function_building_two_models():
     assert two._validated is None            # nothing was accepted, nothing touched the GPU
 
 
+def test_layer_signature_cache_distinguishes_closures():
+    """MaskedCoupling caches what its probe of `bijector_fn` finds per (code object, closure contents, defaults, mask,
+    conditioner shape): haiku_like's apply rebuilds the model on every call and must not pay 16 probe calls each time.
+    The same source with other captured values is another key; mutable captured content is not cached at all."""
+    import normalizing_flows_amd as distrax
+    from normalizing_flows_amd import bijectors
+    mask = (np.arange(2) % 2).astype(bool)
+
+    def make(hi):
+        def rqs_fn(p):
+            return distrax.RationalQuadraticSpline(p, range_min=-hi, range_max=hi)
+        return distrax.MaskedCoupling(mask, rqs_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+
+    bijectors._SIGNATURES.clear()
+    a, b, c = make(8.0), make(4.0), make(8.0)
+    assert a.signature().rqs[1:3] == (-8.0, 8.0) and b.signature().rqs[1:3] == (-4.0, 4.0)
+    assert len(bijectors._SIGNATURES) == 2
+    assert c.signature() is a.signature()                      # same code, same captured value: one probe
+    # other shapes under the same function: another key
+    d = distrax.MaskedCoupling(mask, a._bijector_fn, distrax.make_conditioner((2,), [64, 64], 25, per_dim=True))
+    assert d.signature().rqs[0] == 8 and len(bijectors._SIGNATURES) == 3
+    # a captured array is mutable: no caching, the probe runs
+    box = np.array([8.0])
+
+    def arr_fn(p):
+        return distrax.RationalQuadraticSpline(p, range_min=-float(box[0]), range_max=float(box[0]))
+    e = distrax.MaskedCoupling(mask, arr_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    assert e._signature_cache_key() is None and e.signature().rqs[2] == 8.0
+    box[0] = 6.0
+    f2 = distrax.MaskedCoupling(mask, arr_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    assert f2.signature().rqs[2] == 6.0 and len(bijectors._SIGNATURES) == 3
+    # affine: the column order the probe found travels with the cached signature
+    def swapped(p):
+        log_scale, shift = np.split(p, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, log_scale=log_scale)
+    g1 = distrax.MaskedCoupling(mask, swapped, distrax.make_conditioner((2,), [64, 64], 2))
+    g2 = distrax.MaskedCoupling(mask, swapped, distrax.make_conditioner((2,), [64, 64], 2))
+    g1.signature()
+    g2.signature()
+    assert g1._perm == (1, 0) and g2._perm == (1, 0)
+
+
 def test_lowering_recognises_reference_structures_without_a_gpu():
     import normalizing_flows_amd as distrax
     from normalizing_flows_amd import _lib
