@@ -19,3 +19,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(100): log_prob.apply(params, batch)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
