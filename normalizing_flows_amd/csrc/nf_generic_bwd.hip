@@ -630,8 +630,10 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       if (b.d_small_partials != nullptr && mlp_small_bwd_applicable(Ls, nlin, D)) {
         const float* acts[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int j = 0; j + 1 < nlin; ++j) acts[j] = recorded(j);
-        NF_TRY(launch_mlp_small_bwd(vc, D, Ls, nlin, d_weights, acts, dth, act, gc, D, b.d_small_partials, b.d_grad, n,
-                                    stream));
+        const float* wts[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < nlin; ++j) wts[j] = b.d_wT + b.wT_off[(size_t)l * nlin + j];
+        NF_TRY(launch_mlp_small_bwd(vc, D, Ls, nlin, d_weights, wts, acts, dth, act, gc, D, b.d_small_partials, b.d_grad,
+                                    n, stream, r0 == 0));
         continue;
       }
       const float* gcur = dth;

@@ -302,8 +302,9 @@ int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const 
 bool mlp_small_bwd_applicable(const Linear* Ls, int nlin, int D);
 int mlp_small_bwd_max_blocks();
 int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights,
+                         const float* const* wT /*[nlin]: each Linear transposed, [N][K]*/,
                          const float* const* acts, const float* dth, int act, float* G, int D, float* partial,
-                         float* grad, long long rows, hipStream_t stream);
+                         float* grad, long long rows, hipStream_t stream, bool first_chunk);
 size_t x3_image_halfwords(int K, int N);
 void pack_w_x3(const float* W /*[K][N]*/, int K, int N, unsigned short* image);
 bool gemm_x3_applicable(const float* A, int lda, int N, int K);

@@ -29,6 +29,7 @@ struct MlpSmallBwdArgs {
   const float* x;       // the layer's input [rows][ldx]; the first K[0] columns feed Linear 0
   int ldx;
   const float* W[4];    // [K][N] row-major
+  const float* WT[4];   // the same Linear transposed, [N][K] row-major (the plan keeps these for the data-gradient GEMMs)
   int K[4], N[4];
   const float* a[4];    // a[j]: recorded output of Linear j (after its activation), [rows][N[j]], j < nlin - 1
   const float* dth;     // [rows][N[nlin-1]]
@@ -36,7 +37,10 @@ struct MlpSmallBwdArgs {
   float* G;             // [rows][D]: += g_0 W_1^T
   int D;
   float* partial;       // [gridDim.x][span]: this workgroup's sums, in the plan's weight layout of the layer
-  float* grad_direct;   // one workgroup only: the layer's span of the gradient itself, added to in place
+  float* grad_direct;   // one workgroup only: the layer's span of the gradient itself, no slab and no reduction launch
+  int accumulate;       // grad_direct: add to what is there (a later row chunk) instead of storing (the first chunk:
+                        // the gradient was zeroed before the walk, and a read-modify-write per accumulator tile behind
+                        // a barrier each is a dozen exposed memory round trips -- most of a batch-128 layer's time)
   int span;
   int w_rel[4], b_rel[4];  // where dW_j / db_j sit inside a slab
   long long rows;
@@ -114,15 +118,18 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
   __shared__ __attribute__((aligned(16))) float tiles_lds[4 * 2 * kBwdTileFloats];  // [4 waves][2 tiles]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
+  // W^T [64 n][64 k], zero beyond N and K, from the plan's transposed copies: consecutive threads read consecutive k of
+  // a row and write consecutive LDS words.  (Staged from W [K][N] itself, as the first build did, consecutive threads
+  // wrote LDS words 64 apart -- every store of a wave on one bank -- after a separate zero pass: at the reference's
+  // batch of 128 a layer's launch is mostly such fixed costs.)
 #pragma unroll
   for (int j = 0; j < NLIN; ++j) {
     const int K = a.K[j], N = a.N[j];
     float* WT = smem + j * 4096;
-    for (int q = tid; q < 4096; q += 256) WT[q] = 0.f;
-    __syncthreads();
-    for (int q = tid; q < K * N; q += 256) {
-      const int k = q / N, n = q - k * N;
-      WT[n * 64 + k] = a.W[j][q];
+    const float* __restrict__ src = a.WT[j];
+    for (int q = tid; q < 4096; q += 256) {
+      const int n = q >> 6, k = q & 63;
+      WT[q] = (n < N && k < K) ? src[n * K + k] : 0.f;
     }
   }
   __syncthreads();
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
           if (kk < K && nn < N) {
             const float t = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
             float* dst = slab + a.w_rel[j] + kk * N + nn;
-            *dst = direct ? *dst + t : t;
+            *dst = (direct && a.accumulate) ? *dst + t : t;
           }
         }
         __syncthreads();
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void mlp_small_bwd_kernel(MlpSmallBwdArgs a
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) s += red[w * 128 + q * 64 + c] + red[w * 128 + q * 64 + 32 + c];
-      slab[a.b_rel[j] + tid] = direct ? slab[a.b_rel[j] + tid] + s : s;
+      slab[a.b_rel[j] + tid] = (direct && a.accumulate) ? slab[a.b_rel[j] + tid] + s : s;
     }
     __syncthreads();
   }
@@ -305,9 +312,10 @@ int mlp_small_bwd_max_blocks() { return 256; }
 // The layer's Linears occupy [Ls[0].w_off, Ls[nlin-1].b_off + N) of the plan's weight vector: `grad` points at
 // the gradient vector's start, `partial` holds mlp_small_bwd_max_blocks() slabs of that span.
 int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, const float* weights,
-                         const float* const* acts, const float* dth, int act, float* G, int D, float* partial,
-                         float* grad, long long rows, hipStream_t stream) {
+                         const float* const* wT, const float* const* acts, const float* dth, int act, float* G, int D, float* partial,
+                         float* grad, long long rows, hipStream_t stream, bool first_chunk) {
   MlpSmallBwdArgs a;
+  a.accumulate = first_chunk ? 0 : 1;
   const size_t lo = Ls[0].w_off, hi = Ls[nlin - 1].b_off + Ls[nlin - 1].N;
   a.x = x;
   a.ldx = ldx;
@@ -321,6 +329,7 @@ int launch_mlp_small_bwd(const float* x, int ldx, const Linear* Ls, int nlin, co
   for (int j = 0; j < 4; ++j) {
     const bool live = j < nlin;
     a.W[j] = live ? weights + Ls[j].w_off : nullptr;
+    a.WT[j] = live ? wT[j] : nullptr;
     a.K[j] = live ? Ls[j].K : 0;
     a.N[j] = live ? Ls[j].N : 0;
     a.a[j] = live && j < nlin - 1 ? acts[j] : nullptr;
