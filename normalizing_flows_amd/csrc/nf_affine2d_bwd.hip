@@ -739,6 +739,30 @@ int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream,
   return NF_OK;
 }
 
+// two images from one canonical vector in one launch (the forward and the backward image after an optimiser step)
+__global__ __launch_bounds__(256) void repack2_kernel(const float* __restrict__ canon, const int* __restrict__ src0,
+                                                      const signed char* __restrict__ shift0, float* __restrict__ img0,
+                                                      size_t n0, const int* __restrict__ src1,
+                                                      const signed char* __restrict__ shift1, float* __restrict__ img1,
+                                                      size_t n1) {
+  size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n0) {
+    const int s = src0[e];
+    img0[e] = s < 0 ? 0.f : ldexpf(canon[s], (int)shift0[e]);
+  } else if ((e -= n0) < n1) {
+    const int s = src1[e];
+    img1[e] = s < 0 ? 0.f : ldexpf(canon[s], (int)shift1[e]);
+  }
+}
+
+int launch_repack2(const float* canon, const int* src0, const signed char* shift0, float* img0, size_t n0,
+                   const int* src1, const signed char* shift1, float* img1, size_t n1, hipStream_t stream) {
+  hipLaunchKernelGGL(repack2_kernel, dim3((unsigned)((n0 + n1 + 255) / 256)), dim3(256), 0, stream, canon, src0, shift0,
+                     img0, n0, src1, shift1, img1, n1);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
                   hipStream_t stream) {
   hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, canon, src, shift, img, n);

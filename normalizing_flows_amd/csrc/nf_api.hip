@@ -1396,10 +1396,9 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
   else
     NF_TRY(launch_sgd(canon, grad, count, opt->learning_rate, f->stream, skip, live));
   if (f->path == PATH_AFFINE2D_H64) {
-    NF_TRY(launch_repack(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg,
-                         (size_t)f->desc.num_layers * affine2d::kLayerFloats, f->stream));
-    NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
-                         (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats, f->stream));
+    NF_TRY(launch_repack2(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg, (size_t)f->desc.num_layers * affine2d::kLayerFloats,
+                          t.d_bsrc, t.d_bshift, t.d_bwd_img, (size_t)f->desc.num_layers * affine2d_bwd::kImageFloats,
+                          f->stream));
     t.bwd_x3_stale = true;
   }
   if (trains_through_plan(f)) {

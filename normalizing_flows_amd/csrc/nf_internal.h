@@ -132,6 +132,8 @@ int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream,
 int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream);  // *flag = any NaN / inf in g
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
                   hipStream_t stream);
+int launch_repack2(const float* canon, const int* src0, const signed char* shift0, float* img0, size_t n0,
+                   const int* src1, const signed char* shift1, float* img1, size_t n1, hipStream_t stream);
 
 // ---- path 1b: masked RQS coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2*(3K+1) ----------
 namespace rqs2d {
