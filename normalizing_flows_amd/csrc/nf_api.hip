@@ -185,6 +185,7 @@ struct nf_flow {
   // count lets ranks cross-check that they issued the same number (nf_flow_collective_count).
   unsigned long long collectives = 0;
   hipEvent_t ev_coll = nullptr;
+  hipEvent_t ev_pipe[4] = {};   // large host-buffer calls in chunks: copies on the side stream beside the kernels
   hipStream_t coll_stream = nullptr;  // stream of the last collective, nullptr before the first
   // slots whose local sum has not been all-reduced yet (bit per slot), and the staging for the one
   // batched all-reduce that serves them
@@ -198,6 +199,7 @@ static int get_weights_internal(nf_flow* f, float* packed, size_t count);  // th
 // nf_nll_enqueue: at most this many rows keep the NLL tail on the handle's main stream (see there)
 constexpr long long kInlineTailRows = 1 << 16;
 constexpr long long kZeroCopyRows = 1 << 13;   // 8192 rows: 64 KB in, 32 KB out over the mapping
+constexpr long long kPipeChunkRows = 1 << 18;  // large host-buffer calls of the fused 2-D kernels: 2 MB in, 1 MB out per chunk
 
 namespace nf {
 
@@ -610,6 +612,8 @@ void nf_flow_destroy(nf_flow* f) {
   hipFree(f->d_skip_flag);
   hipFree(f->d_adam_bias);
   if (f->ev_coll) hipEventDestroy(f->ev_coll);
+  for (int q = 0; q < 4; ++q)
+    if (f->ev_pipe[q]) hipEventDestroy(f->ev_pipe[q]);
   if (f->ev0) hipEventDestroy(f->ev0);
   if (f->ev1) hipEventDestroy(f->ev1);
   if (f->stream) hipStreamDestroy(f->stream);
@@ -835,6 +839,50 @@ static int enqueue_log_prob(nf_flow* f, int direction, const float* x_dev, long 
   return run_chain_device(f, io, out_grid);
 }
 
+static int ensure_pipe_events(nf_flow* f) {
+  for (int q = 0; q < 4; ++q)
+    if (!f->ev_pipe[q]) NF_HIP(hipEventCreateWithFlags(&f->ev_pipe[q], hipEventDisableTiming));
+  return NF_OK;
+}
+
+// log_prob of a large HOST batch on the fused 2-D kernels, in chunks: chunk c's kernel runs on the handle's stream while
+// chunk c+1 arrives and chunk c-1 leaves on the side stream (pageable copies block the HOST, so they are issued in the
+// order that keeps a kernel enqueued behind them).  A row's bits do not depend on the batch it is evaluated in, so the
+// result is the unchunked call's.  0.835 -> see DESIGN 5 (profiles/host_path.py).
+static int log_prob_host_pipelined(nf_flow* f, int direction, const float* x, long long rows, float* out) {
+  NF_TRY(ensure_stage(f, rows));
+  NF_TRY(ensure_pipe_events(f));
+  const long long C = kPipeChunkRows;
+  const long long n = (rows + C - 1) / C;
+  auto rows_of = [&](long long c) { return std::min(C, rows - c * C); };
+  NF_HIP(hipStreamSynchronize(f->stream));   // the staging buffers are free
+  // ev_pipe[c & 1]: chunk c has arrived (side stream); ev_pipe[2 + (c & 1)]: chunk c is computed (main stream)
+  auto arrive = [&](long long c) -> int {
+    NF_HIP(hipMemcpyAsync(f->d_x + c * C * 2, x + c * C * 2, sizeof(float) * rows_of(c) * 2, hipMemcpyHostToDevice, f->side));
+    NF_HIP(hipEventRecord(f->ev_pipe[c & 1], f->side));
+    return NF_OK;
+  };
+  auto compute = [&](long long c) -> int {
+    NF_HIP(hipStreamWaitEvent(f->stream, f->ev_pipe[c & 1], 0));
+    NF_TRY(enqueue_log_prob(f, direction, f->d_x + c * C * 2, rows_of(c), f->d_lp + c * C, nullptr, nullptr));
+    NF_HIP(hipEventRecord(f->ev_pipe[2 + (c & 1)], f->stream));
+    return NF_OK;
+  };
+  NF_TRY(arrive(0));
+  NF_TRY(compute(0));
+  for (long long c = 0; c < n; ++c) {
+    if (c + 1 < n) {   // chunk c+1 arrives while c is computed, and its kernel is enqueued BEFORE the host blocks in c's copy out
+      NF_TRY(arrive(c + 1));
+      NF_TRY(compute(c + 1));
+    }
+    NF_HIP(hipStreamWaitEvent(f->side, f->ev_pipe[2 + (c & 1)], 0));
+    NF_HIP(hipMemcpyAsync(out + c * C, f->d_lp + c * C, sizeof(float) * rows_of(c), hipMemcpyDeviceToHost, f->side));
+  }
+  NF_HIP(hipStreamSynchronize(f->side));
+  NF_HIP(hipStreamSynchronize(f->stream));
+  return NF_OK;
+}
+
 // the handle's pinned, device-mapped staging block (false: the mapping is not to be had, callers copy instead)
 static bool ensure_zero_copy(nf_flow* f) {
   if (!f->h_zc) {
@@ -881,6 +929,9 @@ int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, f
       return NF_OK;
     }
   }
+  if (fused2d && D == 2 && rows >= 2 * kPipeChunkRows && f->desc.num_layers <= affine2d::kMaxResidentLayers &&
+      getenv("NF_NO_HOST_PIPELINE") == nullptr)
+    return log_prob_host_pipelined(f, direction, x, rows, out_log_prob);
   NF_TRY(ensure_stage(f, rows));
   NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
   NF_TRY(enqueue_log_prob(f, direction, f->d_x, rows, f->d_lp, nullptr, nullptr));
@@ -1071,6 +1122,34 @@ int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
     NF_TRY(check_device_ptr(out_x, "out_x"));
   }
   NF_TRY(generic::launch_base_sample(dst, rows, D, f->desc.base, seed, f->stream));
+  const bool fused2d = f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64 || f->path == PATH_SPLIT2D_SMALL;
+  if (mem != NF_MEM_DEVICE && fused2d && D == 2 && rows >= 2 * kPipeChunkRows &&
+      f->desc.num_layers <= affine2d::kMaxResidentLayers && getenv("NF_NO_HOST_PIPELINE") == nullptr) {
+    // Transformed.sample(10^6) with a host array out (the scripts' last step): the base draw for all rows in one
+    // launch (the unchunked call's values), the generative walk chunk by chunk, a finished chunk leaving on the side
+    // stream while the next one is walked
+    NF_TRY(ensure_pipe_events(f));
+    const long long C = kPipeChunkRows, n = (rows + C - 1) / C;
+    auto walk = [&](long long c) -> int {
+      ChainIO seg = io;
+      seg.rows = std::min(C, rows - c * C);
+      seg.x = dst + c * C * 2;
+      seg.y = dst + c * C * 2;
+      NF_TRY(run_chain_device(f, seg, nullptr));
+      NF_HIP(hipEventRecord(f->ev_pipe[c & 3], f->stream));
+      return NF_OK;
+    };
+    NF_TRY(walk(0));
+    for (long long c = 0; c < n; ++c) {
+      if (c + 1 < n) NF_TRY(walk(c + 1));
+      NF_HIP(hipStreamWaitEvent(f->side, f->ev_pipe[c & 3], 0));
+      NF_HIP(hipMemcpyAsync(out_x + c * C * 2, dst + c * C * 2, sizeof(float) * std::min(C, rows - c * C) * 2,
+                            hipMemcpyDeviceToHost, f->side));
+    }
+    NF_HIP(hipStreamSynchronize(f->side));
+    NF_HIP(hipStreamSynchronize(f->stream));
+    return NF_OK;
+  }
   io.x = dst;
   io.y = dst;  // every chain kernel may run in place
   NF_TRY(run_chain_device(f, io, nullptr));

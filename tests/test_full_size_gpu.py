@@ -298,6 +298,44 @@ def test_haiku_like_two_models_of_one_architecture(nf_lib):
     assert len(changed) == 1 and changed[0][2][0][0] == "mlp_4/~/linear_0"
 
 
+@pytest.mark.parametrize("kind", ["affine", "rqs", "split"])
+def test_large_host_buffer_calls_are_pipelined_with_the_same_bits(nfa, monkeypatch, kind):
+    """log_prob / sample on large NumPy arrays (>= 2^19 rows) of the fused 2-D kernels run in chunks of 2^18 rows with the
+    copies on the side stream beside the kernels; the results are the unchunked call's, bit for bit (a row's arithmetic
+    does not depend on the batch; the base draw is one launch either way).  A ragged last chunk included."""
+    from normalizing_flows_amd import _lib
+    import ctypes as C
+    if kind == "affine":
+        spec = O.make_affine_spec(8, final_std=0.03)
+        cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
+        f = nfa.CouplingFlow(cfg, spec.layers)
+    elif kind == "rqs":
+        spec = O.make_rqs_spec(4, final_std=0.05)
+        cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=4, hidden=(64, 64), rqs_bins=12,
+                             rqs_range_min=-8.0, rqs_range_max=8.0)
+        f = nfa.CouplingFlow(cfg, spec.layers)
+    else:
+        params, flips = O.make_a_params(8)
+        cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
+                             activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
+        f = nfa.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
+    rows = (1 << 20) + 12345
+    x = O.make_inputs("banana", rows, seed=3)
+    lib = _lib.load()
+
+    def sample(seed):
+        out = np.empty((rows, 2), np.float32)
+        _lib.check(lib.nf_sample(f._h, C.c_uint64(seed), rows, out.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+        return out
+    lp_piped, s_piped = f.log_prob(x), sample(11)
+    monkeypatch.setenv("NF_NO_HOST_PIPELINE", "1")
+    lp_plain, s_plain = f.log_prob(x), sample(11)
+    monkeypatch.delenv("NF_NO_HOST_PIPELINE")
+    assert np.array_equal(lp_piped, lp_plain) and np.isfinite(lp_piped).all()
+    assert np.array_equal(s_piped, s_plain)
+    assert not np.array_equal(s_piped, sample(12))
+
+
 # ------------------------------------------------------------------ host-side hazards
 def test_device_results_need_no_manual_synchronize(nfa):
     """Handles run on non-blocking streams; DeviceArray.to_numpy (nf_memcpy_d2h) and the handle-less device-mode
