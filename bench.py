@@ -522,7 +522,9 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     f.close()
     xm.free()
 
-    # f3: the toy-density generators on the device (src/densities/*.py restated; Philox4x32-10), 8 B written per row
+    # f3: the toy-density generators on the device (src/densities/*.py restated; Philox4x32-10), 8 B written per row;
+    # 2^24 rows (a 2^20-row call is 18 us of launch and tail: profiles/scratch/density_rate.py)
+    rows = 1 << 24
     for dens in ("banana", "gaussian_blobs"):
         out = flow.DeviceArray((rows, 2))
         call = lambda i: _lib.check(lib.nf_density_sample(densities.DENSITIES[dens], C.c_uint64(77 + i), rows, out.ptr,  # noqa: E731
@@ -539,9 +541,9 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
             walls.append(time.perf_counter() - t0)
         walls.sort()
         wall = walls[len(walls) // 2]
-        line("f3", f"density generator {dens}, 2^20 rows into HBM", "density_sample_kernel", rows, wall, wall * 1e3,
-             walls, "rows/s", hbm(rows, 8, wall * 1e3, "wall-clock (the generator runs on the default stream); "
-                                  "transcendental-issue bound, 8 B written per row"))
+        line("f3", f"density generator {dens}, 2^24 rows into HBM", "density_sample_kernel", rows, wall, wall * 1e3,
+             walls, "rows/s", hbm(rows, 8, wall * 1e3, "wall-clock (the generator runs on the default stream); bound by "
+                                  "vector issue (Philox4x32-10 + Box-Muller per row), 8 B written per row"))
         out.free()
     return res
 
