@@ -491,15 +491,18 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
                             activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
     f = flow.CouplingFlow(a_cfg, a_layers)
     opt = training.sgd(1e-3)
-    step = lambda i: f.train_step(xd, opt, want_nll=False)  # noqa: E731
-    wall, ev_ms, walls = measure(f, step, steps, warm, args.min_seconds)
-    line("f2", "training step (forward + backward + SGD), src/real_nvp.py flow (MLP 1-4-2), 8 layers, batch 2^20",
-         f.kernel_name, rows, wall, ev_ms, walls, "samples/s",
-         hbm(rows, 8 + 8 + 16 + 8, ev_ms, "forward reads x and writes z (16 B), the one backward launch reads z (8 B): "
-             "no per-layer state through HBM; vector-issue bound"))
-    f.close()
     xd.free()
     x128.free()
+    rows24 = 1 << 24   # (75 us per step at 2^20 rows is launch and tail: 1.4e10 samples/s)
+    xa = next(densities.get_density("energy2")(seed=2123, batch_size=rows24, num_batches=1, device=True))
+    step = lambda i: f.train_step(xa, opt, want_nll=False)  # noqa: E731
+    wall, ev_ms, walls = measure(f, step, steps, warm, args.min_seconds)
+    line("f2", "training step (forward + backward + SGD), src/real_nvp.py flow (MLP 1-4-2), 8 layers, batch 2^24",
+         f.kernel_name, rows24, wall, ev_ms, walls, "samples/s",
+         hbm(rows24, 8 + 8 + 16 + 8, ev_ms, "forward reads x and writes z (16 B), the one backward launch reads z (8 B): "
+             "no per-layer state through HBM; vector-issue bound"))
+    f.close()
+    xa.free()
 
     # f2, image shape: the reference's own MNIST training configuration (src/maf_mnist.py:34-89,159-168: 8 layers, 784-D,
     # MLP 512 x 3, K = 8, batch 128) -- weight-bound: every step reads the 46 M live weights twice, writes their gradient
