@@ -17,8 +17,11 @@ by +-8 % from launch to launch -- so blocks are repeated until >= 0.5 s of them 
 (at most 200); `value` / `ms_per_step` are the MEDIAN block's, `block_ms` carries
 min / median / max and the count.
 
-N > 1 is launched by `python -m torch.distributed.run`; torch.distributed (gloo,
-CPU) is used only for the rendezvous, the barrier and the max-over-ranks of the
+N > 1: one rank per GPU, launched by `python -m torch.distributed.run` (the driver) or,
+typed as `python bench.py --gpus N` without a launcher, by this script itself
+(`spawn_ranks`: the parent starts N fresh rank processes before anything touches the GPU,
+relays rank 0's line, ends everybody if one rank fails or 600 s pass).  torch.distributed
+(gloo, CPU) is used only for the rendezvous, the barrier and the max-over-ranks of the
 timing.  All GPU work goes through libnf_hip.so (own stream, own RCCL
 communicator); torch never touches the device.
 
@@ -118,6 +121,80 @@ def cpu_baseline(layers, layers4, density):
                  "value": rows * reps_np / dt_np, "unit": "evals/s", "cores": usable_cpus(), "calls": reps_np}]}
 
 
+def spawn_ranks(n, argv, worker=None, timeout_s=None):
+    """`python bench.py --gpus N` typed as it stands (no launcher, WORLD_SIZE unset, N > 1): this process becomes the
+    PARENT of N fresh rank processes and never touches the GPU itself -- nothing of libnf_hip, HIP or torch is loaded
+    before or after the children start, so no process that has initialised a device is ever re-executed.  Every child
+    is this same script (or `worker`, NF_BENCH_WORKER: the stub of tests/test_abi_and_host.py) with RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT in its environment -- what `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N` would have set -- in its own process group.  Rank 0's stdout
+    (the one JSON line) is relayed when ALL ranks have exited with 0; the first rank to fail, or NF_BENCH_SPAWN_TIMEOUT
+    (600 s) passing, ends every other rank (SIGTERM to the group, SIGKILL after 5 s) and the parent exits non-zero
+    (the failed rank's code, 124 for the limit) without printing a result line.  Returns the exit code."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    worker = worker or os.environ.get("NF_BENCH_WORKER") or os.path.abspath(__file__)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("NF_BENCH_SPAWN_TIMEOUT", "600"))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+
+    def end_all():
+        for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            live = [p for p in procs if p.poll() is None]
+            if not live:
+                return
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)     # the child's own group (start_new_session): it and whatever it started
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + wait
+            while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+
+    code = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+            procs.append(subprocess.Popen([sys.executable, worker] + list(argv), env=env, start_new_session=True,
+                                          stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+        deadline = time.monotonic() + timeout_s
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed:
+                r, c = failed[0]
+                print(f"bench.py: rank {r} of {n} exited with {c}; ending the other ranks", file=sys.stderr)
+                code = c if 0 < c < 256 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                running = [r for r, c in enumerate(codes) if c is None]
+                print(f"bench.py: ranks {running} of {n} still running after {timeout_s:.0f} s; ending them",
+                      file=sys.stderr)
+                code = 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        code = 130
+    finally:
+        end_all()
+    if code == 0:
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,13 +211,13 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[0], [2], [4] (N = 1 only)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # typed without a launcher: become the parent of N rank processes (before anything here touches the GPU)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run "
-                     "--nproc-per-node N (one rank per GPU)")
+    if world != args.gpus:   # under a launcher its world size is the truth
         args.gpus = world
 
     from normalizing_flows_amd import _lib, densities, flow

@@ -15,6 +15,7 @@ has no kernel for raises `NotImplementedError`; a missing library or GPU raises
 """
 from __future__ import annotations
 
+import types
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -169,7 +170,24 @@ class _LayerSignature:
         return (self.kind, self.event_shape, self.hidden, self.activation, self.rqs)
 
 
-_SIGNATURES: dict = {}   # MaskedCoupling._signature_cache_key() -> (_LayerSignature, column order)
+_SIGNATURES: dict = {}   # MaskedCoupling._signature_cache_key()[0] -> (_LayerSignature, column order, kept objects)
+
+_BY_IDENTITY = (types.ModuleType, type, types.FunctionType, types.BuiltinFunctionType, types.MethodType)
+
+
+def _key_part(v, keep: list, depth: int = 0):
+    """One captured value as a hashable key part, or None if it has no safe one (see _signature_cache_key)."""
+    if isinstance(v, (bool, int, float, str, bytes, type(None))):
+        return ("v", type(v).__name__, v)
+    if isinstance(v, np.generic):
+        return ("g", type(v).__name__, v.item())
+    if isinstance(v, tuple) and depth < 4:
+        parts = tuple(_key_part(e, keep, depth + 1) for e in v)
+        return None if any(p is None for p in parts) else ("t", parts)
+    if isinstance(v, _BY_IDENTITY):
+        keep.append(v)
+        return ("o", id(v))
+    return None
 
 
 class MaskedCoupling(Bijector):
@@ -217,47 +235,60 @@ class MaskedCoupling(Bijector):
     def _signature_cache_key(self):
         """haiku_like's apply re-runs the model-building function on every call, so every call meets new
         MaskedCoupling objects around a NEW closure of the same `bijector_fn` source.  What the probe below finds
-        depends on that function's code, on what it closes over and on the layer's shapes only: cached per
-        (code object, closure contents, defaults, mask, conditioner shape) -- 8 probes of 2 calls each were 300 us of
-        a 445 us `log_prob.apply(params, batch)` at the reference's batch of 128.  None: not cacheable."""
+        depends on that function's code, on what it closes over, on the module globals it reads and on the layer's
+        shapes only: cached per (code object, closure contents, globals read, defaults, mask, conditioner shape) -- 8
+        probes of 2 calls each were 300 us of a 445 us `log_prob.apply(params, batch)` at the reference's batch of 128.
+        Returns (key, keep) or None (not cacheable: the probe runs every time).  Values enter the key BY VALUE
+        (Python scalars, NumPy scalars -- a fresh `np.float32(...)` per call is the usual case -- strings, tuples of
+        those); modules, classes and functions by identity, with a strong reference in `keep` that the cache entry
+        holds, so that their id cannot be recycled while the entry lives; anything else (arrays, lists, config
+        objects, 0-d device scalars ...) makes the layer uncacheable rather than keyed by an address."""
         fn = self._bijector_fn
         code = getattr(fn, "__code__", None)
         if code is None:
             return None
+        keep: list = []
         parts = [code]
         try:
             for cell in (fn.__closure__ or ()):
-                v = cell.cell_contents
-                if isinstance(v, (int, float, str, bool, bytes, type(None), tuple)):
-                    parts.append(("v", v))
-                elif isinstance(v, (np.ndarray, list, dict, set)):
-                    return None                       # mutable content: probe every time
-                else:
-                    parts.append(("o", id(v)))        # modules, classes, functions: identity
-            parts.append(("d", fn.__defaults__, tuple(sorted((fn.__kwdefaults__ or {}).items()))))
+                part = _key_part(cell.cell_contents, keep)
+                if part is None:
+                    return None
+                parts.append(part)
+            glob = getattr(fn, "__globals__", {})
+            for name in code.co_names:       # globals (and attribute names: those are not in __globals__, or are
+                if name in glob:             # keyed harmlessly) the function may read
+                    part = _key_part(glob[name], keep)
+                    if part is None:
+                        return None
+                    parts.append((name, part))
+            part = _key_part((fn.__defaults__, tuple(sorted((fn.__kwdefaults__ or {}).items()))), keep)
+            if part is None:
+                return None
+            parts.append(part)
             c = self._conditioner
             parts.append((self._mask.shape, self._mask.tobytes(), c.in_size, c.out_size, c.params_per_dim,
                           c.hidden_sizes, c.activation))
             key = tuple(parts)
             hash(key)
-            return key
+            return key, keep
         except (TypeError, ValueError):
             return None
 
     def signature(self) -> _LayerSignature:
         if self._sig is not None:
             return self._sig
-        key = self._signature_cache_key()
-        if key is not None:
-            hit = _SIGNATURES.get(key)
+        keyed = self._signature_cache_key()
+        if keyed is not None:
+            hit = _SIGNATURES.get(keyed[0])
             if hit is not None:
-                self._sig, self._perm = hit
+                self._sig, self._perm = hit[0], hit[1]
                 return self._sig
         sig = self._probe_signature()
-        if key is not None:
+        if keyed is not None:
             if len(_SIGNATURES) > 256:
                 _SIGNATURES.clear()
-            _SIGNATURES[key] = (sig, self._perm)
+            _SIGNATURES[keyed[0]] = (sig, self._perm, keyed[1])   # keyed[1]: the identity-keyed objects, kept alive
         return sig
 
     def _probe_signature(self) -> _LayerSignature:

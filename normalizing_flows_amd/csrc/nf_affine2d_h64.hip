@@ -410,12 +410,7 @@ int max_grid() { return 256; }
 
 template <int T, int WAVES, int INV>
 static int launch_t(const Params& p, int grid, size_t lds_bytes, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  NF_DYN_LDS(160 * 1024, &chain_kernel<T, WAVES, INV>);
   hipLaunchKernelGGL((chain_kernel<T, WAVES, INV>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
@@ -432,8 +427,8 @@ static int launch_dir(const Params& p, int grid, size_t lds_bytes, hipStream_t s
 struct Tune { int T, waves; };
 static Tune read_tune() {
   Tune t = {2, 16};
-  const char* e = getenv("NF_AFFINE2D_TUNE");
-  if (e) sscanf(e, "%d,%d", &t.T, &t.waves);
+  const int* e = switches().affine2d_tune;
+  if (e[0]) { t.T = e[0]; t.waves = e[1]; }
   return t;
 }
 
@@ -445,6 +440,7 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
     return NF_ERR_INVALID;
   }
   const Tune tune = read_tune();
+  const bool tuned = switches().affine2d_tune[0] != 0;
   Params p;
   p.wimg = wimg;
   p.io = io;
@@ -455,18 +451,14 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
   // (NF_AFFINE2D_NO_MSPLIT=1: the one-wave-per-tile geometries below, for A/B)
   {
     const long long tiles = (io.rows + 31) / 32;
-    if (tiles >= 1 && tiles <= 2LL * cap && getenv("NF_AFFINE2D_TUNE") == nullptr && getenv("NF_AFFINE2D_NO_MSPLIT") == nullptr) {
+    if (tiles >= 1 && tiles <= 2LL * cap && !tuned && !switches().affine2d_no_msplit) {
       const int per = tiles <= cap ? 1 : 2;
       const int grid = (int)((tiles + per - 1) / per);
       if (out_grid) *out_grid = grid;
-      static bool attr_ms = false;
-      if (!attr_ms) {
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel_msplit<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr_ms = true;
-      }
+      NF_DYN_LDS(159 * 1024, &chain_kernel_msplit<2, 0>);
+      NF_DYN_LDS(159 * 1024, &chain_kernel_msplit<2, 1>);
+      NF_DYN_LDS(159 * 1024, &chain_kernel_msplit<4, 0>);
+      NF_DYN_LDS(159 * 1024, &chain_kernel_msplit<4, 1>);
       if (per == 1) {
         if (io.inverse_op) hipLaunchKernelGGL((chain_kernel_msplit<2, 1>), dim3(grid), dim3(128), lds_bytes, stream, p);
         else hipLaunchKernelGGL((chain_kernel_msplit<2, 0>), dim3(grid), dim3(128), lds_bytes, stream, p);
@@ -481,7 +473,7 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, int grid
   int waves = tune.waves == 8 ? 8 : (tune.waves == 4 ? 4 : 16);
   // small batches: waves of one workgroup share the CU's four MFMA pipes, so fewer waves per
   // workgroup and more workgroups finish sooner (4096 rows: 35 us -> see profiles/bench_configs.py)
-  if (getenv("NF_AFFINE2D_TUNE") == nullptr) {
+  if (!tuned) {
     if (io.rows <= (long long)cap * 4 * 32) waves = 4;
     else if (io.rows <= (long long)cap * 8 * 32) waves = 8;
   }

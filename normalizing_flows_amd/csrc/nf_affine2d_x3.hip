@@ -293,12 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES >= 8 ? WAVES / 4 : 2) void chain_
 template <int T, int WAVES, int INV>
 static int launch_t(const Params& p, int grid, hipStream_t stream) {
   const size_t lds_bytes = 2 * (size_t)kLayerFloats * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  NF_DYN_LDS(160 * 1024, &chain_kernel<T, WAVES, INV>);
   hipLaunchKernelGGL((chain_kernel<T, WAVES, INV>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
@@ -315,7 +310,7 @@ int launch(const float* wimg, int first_mask_parity, const ChainIO& io, hipStrea
   p.io = io;
   p.first_mask_parity = first_mask_parity;
   int T = 4, waves = 8;  // NF_AFFINE2D_X3_TUNE="T,WAVES": development knob (measured: profiles/x3_tune.py)
-  if (const char* e = getenv("NF_AFFINE2D_X3_TUNE")) sscanf(e, "%d,%d", &T, &waves);
+  if (const int* e = switches().affine2d_x3_tune; e[0]) { T = e[0]; waves = e[1]; }
   if (waves != 16 && waves != 4) waves = 8;
   if (T != 1 && T != 2 && T != 4) T = 2;
   if (waves == 16 && T != 1) T = 1;

@@ -7,7 +7,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
+#include <set>
+#include <unordered_set>
+#include <utility>
 
 namespace nf {
 
@@ -26,6 +30,73 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
   return e == hipErrorNoDevice ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
 }
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  int dev = 0;
+  NF_HIP(hipGetDevice(&dev));
+  // fast path: what THIS thread has already seen done on this device (no lock; filled only after the global set says so)
+  struct Seen { int dev = -1; std::unordered_set<const void*> kernels; };
+  static thread_local Seen seen;
+  if (seen.dev != dev) { seen.dev = dev; seen.kernels.clear(); }
+  if (seen.kernels.count(kernel)) return NF_OK;
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  {
+    std::lock_guard<std::mutex> lock(mu);  // held across the HIP call: a second thread waits until the attribute is set
+    if (!done.count({dev, kernel})) {
+      NF_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      done.insert({dev, kernel});
+    }
+  }
+  seen.kernels.insert(kernel);
+  return NF_OK;
+}
+
+Switches Switches::from_env() {
+  Switches s;
+  auto on = [](const char* name) { return getenv(name) != nullptr; };
+  s.force_generic = on("NF_FORCE_GENERIC");
+  s.no_pad = on("NF_NO_PAD");
+  s.no_zero_copy = on("NF_NO_ZERO_COPY");
+  s.no_host_pipeline = on("NF_NO_HOST_PIPELINE");
+  s.gemm_no_full = on("NF_GEMM_NO_FULL");
+  s.gemm_simple = on("NF_GEMM_SIMPLE");
+  s.no_splitk = on("NF_NO_SPLITK");
+  s.no_k5 = on("NF_NO_K5");
+  s.rqs_simple = on("NF_RQS_SIMPLE");
+  s.no_mlp_small = on("NF_NO_MLP_SMALL");
+  s.no_mlp_small_bwd = on("NF_NO_MLP_SMALL_BWD");
+  s.affine2d_no_msplit = on("NF_AFFINE2D_NO_MSPLIT");
+  s.no_rqs2d_bwd = on("NF_NO_RQS2D_BWD");
+  s.no_small_m = on("NF_NO_SMALL_M");
+  auto pair = [](const char* name, int* out) {
+    if (const char* e = getenv(name)) {
+      int t = 0, w = 0;
+      if (sscanf(e, "%d,%d", &t, &w) == 2 && t > 0 && w > 0) { out[0] = t; out[1] = w; }
+    }
+  };
+  pair("NF_AFFINE2D_TUNE", s.affine2d_tune);
+  pair("NF_AFFINE2D_X3_TUNE", s.affine2d_x3_tune);
+  pair("NF_RQS2D_TUNE", s.rqs2d_tune);
+  pair("NF_RQS2D_X3_TUNE", s.rqs2d_x3_tune);
+  if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) s.split2d_samples = v; }
+  if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= kBlockSumCap) s.split2d_grid = v; }
+  if (const char* e = getenv("NF_INLINE_TAIL_LG")) {   // development; a shift count outside [0, 63] would be undefined
+    int lg = atoi(e);
+    lg = lg < 0 ? 0 : (lg > 40 ? 40 : lg);
+    s.inline_tail_rows = 1LL << lg;
+  }
+  return s;
+}
+
+static thread_local const Switches* g_switches = nullptr;
+const Switches& switches() {
+  if (g_switches) return *g_switches;
+  static const Switches process_default = Switches::from_env();  // handle-less entry points; thread-safe static init
+  return process_default;
+}
+UseSwitches::UseSwitches(const Switches* s) : prev(g_switches) { g_switches = s; }
+UseSwitches::~UseSwitches() { g_switches = prev; }
 
 enum Path { PATH_AFFINE2D_H64 = 0, PATH_SPLIT2D_SMALL = 1, PATH_GENERIC = 2, PATH_RQS2D_H64 = 3 };
 
@@ -111,6 +182,7 @@ using namespace nf;
 
 struct nf_flow {
   nf_flow_desc desc;
+  Switches sw;  // the environment switches as they stood when the handle was created
   int device = 0;
   int path = PATH_GENERIC;
   hipStream_t stream = nullptr;
@@ -497,14 +569,15 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
   nf_flow* f = new (std::nothrow) nf_flow();
   if (!f) { set_error("out of host memory"); return NF_ERR_INVALID; }
   f->desc = *desc;
+  f->sw = Switches::from_env();
   nf_flow_weight_count(desc, &f->user_count);
   {
     const nf_flow_desc& u = *desc;
     const bool fused_kind = u.kind == NF_KIND_AFFINE_MASKED ||
                             (u.kind == NF_KIND_RQS_MASKED && rqs2d::supported_bins(u.rqs_bins) &&
-                             getenv("NF_FORCE_GENERIC") == nullptr);
+                             !f->sw.force_generic);
     if (fused_kind && u.event_dim == 2 && u.num_hidden == 2 && u.activation == NF_ACT_RELU && u.hidden[0] <= 64 &&
-        u.hidden[1] <= 64 && (u.hidden[0] < 64 || u.hidden[1] < 64) && getenv("NF_NO_PAD") == nullptr) {
+        u.hidden[1] <= 64 && (u.hidden[0] < 64 || u.hidden[1] < 64) && !f->sw.no_pad) {
       f->padded = true;
       f->desc.hidden[0] = f->desc.hidden[1] = 64;
       std::vector<int> in, out;
@@ -535,7 +608,7 @@ int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow) {
     f->path = PATH_SPLIT2D_SMALL;
   else if (d.kind == NF_KIND_RQS_MASKED && d.event_dim == 2 && d.num_hidden == 2 && d.hidden[0] == 64 &&
            d.hidden[1] == 64 && d.activation == NF_ACT_RELU && rqs2d::supported_bins(d.rqs_bins) &&
-           getenv("NF_FORCE_GENERIC") == nullptr)
+           !f->sw.force_generic)
     f->path = PATH_RQS2D_H64;
   else
     f->path = PATH_GENERIC;
@@ -623,6 +696,7 @@ void nf_flow_destroy(nf_flow* f) {
 static int set_weights_internal(nf_flow* f, const float* packed, size_t count);
 
 int nf_flow_set_weights(nf_flow* f, const float* packed, size_t count) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   if (!packed) { set_error("packed is NULL"); return NF_ERR_INVALID; }
   if (count != f->user_count) {
@@ -674,6 +748,7 @@ static int set_weights_internal(nf_flow* f, const float* packed, size_t count) {
       NF_HIP(hipMemset(f->train.d_m, 0, oc * sizeof(float)));
       NF_HIP(hipMemset(f->train.d_v, 0, oc * sizeof(float)));
       f->train.step = 0;
+      if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }  // the device-side count restarts too
       f->train.canon_stale = false;
     }
     return NF_OK;
@@ -688,6 +763,9 @@ static int set_weights_internal(nf_flow* f, const float* packed, size_t count) {
     NF_HIP(hipMemset(f->train.d_m, 0, oc * sizeof(float)));
     NF_HIP(hipMemset(f->train.d_v, 0, oc * sizeof(float)));
     f->train.step = 0;
+    // the device-side count of APPLIED steps (skip_nonfinite_updates) restarts with the moments: left alone, Adam's
+    // bias correction would continue from the old t on zeroed moments
+    if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     f->train.canon_stale = false;
   }
   if (f->train.ready && f->path == PATH_RQS2D_H64) {
@@ -712,6 +790,7 @@ int nf_flow_kernel_name(const nf_flow* f, char* buf, size_t buf_len) {
 }
 
 int nf_flow_set_option(nf_flow* f, const char* name, const char* value) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f || !name || !value) { set_error("bad argument"); return NF_ERR_INVALID; }
   if (strcmp(name, "hidden_matmul") == 0) {
     const bool on = strcmp(value, "bf16x3") == 0;
@@ -779,6 +858,7 @@ int nf_flow_get_option(const nf_flow* f, const char* name, char* buf, size_t buf
 }
 
 int nf_flow_synchronize(nf_flow* f) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   NF_HIP(hipStreamSynchronize(f->stream));
   if (f->reduce_pending) NF_TRY(flush_pending_reductions(f));  // collective: every rank synchronises alike
@@ -788,6 +868,7 @@ int nf_flow_synchronize(nf_flow* f) {
 
 int nf_chain_apply(nf_flow* f, int direction, int layer_begin, int layer_end, const float* x,
                    int64_t rows, float* y, float* logdet, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x, rows));
   if (direction < NF_DIR_CHAIN_FORWARD || direction > NF_DIR_LAST_TO_FIRST_INVERSE) {
     set_error("unknown direction %d", direction); return NF_ERR_INVALID;
@@ -901,11 +982,13 @@ static bool ensure_zero_copy(nf_flow* f) {
 }
 
 int nf_log_prob(nf_flow* f, const float* x, int64_t rows, float* out_log_prob, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f) { set_error("flow handle is NULL"); return NF_ERR_INVALID; }
   return nf_chain_log_prob(f, default_direction(f), x, rows, out_log_prob, mem);
 }
 
 int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, float* out_log_prob, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x, rows));
   if (direction < NF_DIR_CHAIN_FORWARD || direction > NF_DIR_LAST_TO_FIRST_INVERSE) {
     set_error("unknown direction %d", direction); return NF_ERR_INVALID;
@@ -918,7 +1001,7 @@ int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, f
   }
   const int D = f->desc.event_dim;
   const bool fused2d = f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64 || f->path == PATH_SPLIT2D_SMALL;
-  if (fused2d && D == 2 && rows <= kZeroCopyRows && getenv("NF_NO_ZERO_COPY") == nullptr) {
+  if (fused2d && D == 2 && rows <= kZeroCopyRows && !f->sw.no_zero_copy) {
     // Two pageable copies cost the host ~10 us each beside a 25 us kernel (76 us per call at batch 128): the fused
     // kernels read x once and write log_prob once, so both go over the mapping of one pinned buffer instead.
     if (ensure_zero_copy(f)) {
@@ -930,7 +1013,7 @@ int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, f
     }
   }
   if (fused2d && D == 2 && rows >= 2 * kPipeChunkRows && f->desc.num_layers <= affine2d::kMaxResidentLayers &&
-      getenv("NF_NO_HOST_PIPELINE") == nullptr)
+      !f->sw.no_host_pipeline)
     return log_prob_host_pipelined(f, direction, x, rows, out_log_prob);
   NF_TRY(ensure_stage(f, rows));
   NF_HIP(hipMemcpyAsync(f->d_x, x, sizeof(float) * rows * D, hipMemcpyHostToDevice, f->stream));
@@ -942,6 +1025,7 @@ int nf_chain_log_prob(nf_flow* f, int direction, const float* x, int64_t rows, f
 
 int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t rows_global,
                    float* out_log_prob_dev, int slot) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x_dev, rows_local));
   if (slot < 0 || slot >= NF_NLL_SLOTS) { set_error("slot must be 0..%d", NF_NLL_SLOTS - 1); return NF_ERR_INVALID; }
   if (rows_global < rows_local || rows_global < 1) { set_error("rows_global must be >= rows_local and >= 1"); return NF_ERR_INVALID; }
@@ -958,7 +1042,7 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
   // 2^21 -- 13.2 against 15.8 us per step at 2^20; from 2^22 on the side stream wins again:
   // profiles/scratch/nll_step_split2d.py)
   long long inline_rows = f->path == PATH_SPLIT2D_SMALL ? (1LL << 21) : kInlineTailRows;
-  if (const char* e = getenv("NF_INLINE_TAIL_LG")) inline_rows = 1LL << atoi(e);   // development
+  if (f->sw.inline_tail_rows) inline_rows = f->sw.inline_tail_rows;   // NF_INLINE_TAIL_LG, development
   if (f->comm == nullptr && f->h_ring_dev != nullptr && rows_local > 0 && rows_local <= inline_rows) {
     NF_TRY(enqueue_log_prob(f, default_direction(f), x_dev, rows_local, out_log_prob_dev, sums, &grid));
     NF_TRY(launch_sum_blocks(sums, grid, f->d_sum + slot, f->stream, f->h_ring_dev + slot));
@@ -992,6 +1076,7 @@ int nf_nll_enqueue(nf_flow* f, const float* x_dev, int64_t rows_local, int64_t r
 }
 
 int nf_nll_result(nf_flow* f, int slot, double* out_nll) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f || !out_nll) { set_error("bad argument"); return NF_ERR_INVALID; }
   if (slot < 0 || slot >= NF_NLL_SLOTS || f->ring_rows[slot] == 0) {
     set_error("slot %d holds no result", slot); return NF_ERR_STATE;
@@ -1003,6 +1088,7 @@ int nf_nll_result(nf_flow* f, int slot, double* out_nll) {
 
 int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, float* out_log_prob,
            double* out_nll, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x, rows_local));
   if (!out_nll) { set_error("out_nll is NULL"); return NF_ERR_INVALID; }
   if (mem == NF_MEM_DEVICE) {
@@ -1012,7 +1098,7 @@ int nf_nll(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, 
   }
   const int D = f->desc.event_dim;
   const bool fused2d = f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64 || f->path == PATH_SPLIT2D_SMALL;
-  if (fused2d && D == 2 && rows_local > 0 && rows_local <= kZeroCopyRows && getenv("NF_NO_ZERO_COPY") == nullptr &&
+  if (fused2d && D == 2 && rows_local > 0 && rows_local <= kZeroCopyRows && !f->sw.no_zero_copy &&
       ensure_zero_copy(f)) {   // as nf_chain_log_prob: x and log_prob over the mapping of one pinned block
     memcpy(f->h_zc, x, sizeof(float) * rows_local * 2);
     float* lp = f->h_zc_dev + kZeroCopyRows * 2;
@@ -1102,6 +1188,7 @@ int nf_density_sample(int density, uint64_t seed, int64_t rows, float* out, int 
 }
 
 int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, out_x, rows));
   if (rows == 0) return NF_OK;
   const int D = f->desc.event_dim;
@@ -1124,7 +1211,7 @@ int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
   NF_TRY(generic::launch_base_sample(dst, rows, D, f->desc.base, seed, f->stream));
   const bool fused2d = f->path == PATH_AFFINE2D_H64 || f->path == PATH_RQS2D_H64 || f->path == PATH_SPLIT2D_SMALL;
   if (mem != NF_MEM_DEVICE && fused2d && D == 2 && rows >= 2 * kPipeChunkRows &&
-      f->desc.num_layers <= affine2d::kMaxResidentLayers && getenv("NF_NO_HOST_PIPELINE") == nullptr) {
+      f->desc.num_layers <= affine2d::kMaxResidentLayers && !f->sw.no_host_pipeline) {
     // Transformed.sample(10^6) with a host array out (the scripts' last step): the base draw for all rows in one
     // launch (the unchunked call's values), the generative walk chunk by chunk, a finished chunk leaving on the side
     // stream while the next one is walked
@@ -1169,6 +1256,8 @@ int nf_debug_read_f2(const float* x_dev, int64_t rows, float* out_dev) {
 
 int nf_debug_gemm(const float* a_dev, int lda, const float* w_dev, const float* bias_dev, float* c_dev, int ldc,
                   int m, int n, int k, int act) {
+  const Switches sw_now = Switches::from_env();  // a diagnostic without a handle: the environment as it stands
+  UseSwitches use_sw(&sw_now);
   if (!a_dev || !w_dev || !bias_dev || !c_dev || m < 1 || n < 1 || k < 1 || lda < k || ldc < n || act < 0 || act > 2) {
     set_error("bad argument");
     return NF_ERR_INVALID;
@@ -1415,6 +1504,7 @@ extern "C" {
 
 int nf_nll_grad(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, double* out_nll,
                 float* out_grad, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x, rows_local));
   if (rows_local < 1 || rows_global < rows_local) { set_error("need 1 <= rows_local <= rows_global"); return NF_ERR_INVALID; }
   if (!out_grad) { set_error("out_grad is NULL"); return NF_ERR_INVALID; }
@@ -1441,6 +1531,7 @@ int nf_nll_grad(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_glo
 
 int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_global, const nf_optimizer* opt,
                   double* out_nll, int mem) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   NF_TRY(check_ready(f, x, rows_local));
   if (!opt) { set_error("opt is NULL"); return NF_ERR_INVALID; }
   if (opt->kind != NF_OPT_SGD && opt->kind != NF_OPT_ADAM) { set_error("unknown optimizer %d", opt->kind); return NF_ERR_INVALID; }
@@ -1502,6 +1593,7 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
 }
 
 int nf_flow_get_weights(nf_flow* f, float* packed, size_t count) {
+  UseSwitches use_sw(f ? &f->sw : nullptr);
   if (!f || !packed) { set_error("bad argument"); return NF_ERR_INVALID; }
   if (!f->have_weights) { set_error("nf_flow_set_weights has not been called"); return NF_ERR_STATE; }
   if (count != f->user_count) { set_error("expected room for %zu weights, got %zu", f->user_count, count); return NF_ERR_INVALID; }

@@ -260,15 +260,9 @@ template <int KB>
 static int launch_gemm_x3_rqs_k(const float* A, int lda, const unsigned short* wimg, const float* bias, float* y,
                                 float* ldpart, int M, int Npad, int K, int D, int par, int inverse,
                                 const RqsConst& rc, hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t lds_bytes = 2 * (size_t)kTileU4 * sizeof(uint4);
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_rqs_kernel<KB, 0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_rqs_kernel<KB, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+    const size_t lds_bytes = 2 * (size_t)kTileU4 * sizeof(uint4);
+  NF_DYN_LDS(64 * 1024, &gemm_x3_rqs_kernel<KB, 0>);
+  NF_DYN_LDS(64 * 1024, &gemm_x3_rqs_kernel<KB, 1>);
   const int gx = Npad / XBN, gy = (M + XBM - 1) / XBM;
   const uint4* w = reinterpret_cast<const uint4*>(wimg);
   if (inverse)
@@ -301,13 +295,8 @@ bool gemm_x3_applicable(const float* A, int lda, int N, int K) {
 
 int launch_gemm_x3(const float* A, int lda, const unsigned short* wimg, const float* bias, float* Cm, int ldc,
                    int M, int N, int K, int act, hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t lds_bytes = 2 * (size_t)kTileU4 * sizeof(uint4);
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+    const size_t lds_bytes = 2 * (size_t)kTileU4 * sizeof(uint4);
+  NF_DYN_LDS(64 * 1024, &gemm_x3_kernel);
   const int gx = (N + XBN - 1) / XBN, gy = (M + XBM - 1) / XBM;
   hipLaunchKernelGGL(gemm_x3_kernel, dim3(gx * gy), dim3(256), lds_bytes, stream, A, lda,
                      reinterpret_cast<const uint4*>(wimg), bias, Cm, ldc, M, N, K, act, gx, gy);

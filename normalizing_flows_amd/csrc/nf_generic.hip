@@ -344,7 +344,7 @@ __device__ __forceinline__ void gemm_full_mainloop(const float* __restrict__ A, 
 }
 
 // K, N as gemm_full_mainloop needs them?  (alignment of the bases and of lda is the fast path's own condition)
-static inline bool gemm_full_ok(int N, int K) { return K >= FBK && (K % 4) == 0 && (N % FBN) == 0 && getenv("NF_GEMM_NO_FULL") == nullptr; }
+static inline bool gemm_full_ok(int N, int K) { return K >= FBK && (K % 4) == 0 && (N % FBN) == 0 && !switches().gemm_no_full; }
 
 template <bool FULL>
 __global__ __launch_bounds__(256, 4) void gemm_fast_kernel(
@@ -493,25 +493,14 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
                        int M, int N, int K, int act, hipStream_t stream, const float* aux) {
   const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
-  if (aligned && N >= 128 && K >= 32 && getenv("NF_GEMM_SIMPLE") == nullptr) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      attr_set = true;
-    }
+  if (aligned && N >= 128 && K >= 32 && !switches().gemm_simple) {
+    NF_DYN_LDS(80 * 1024, &gemm_fast_kernel<false>);
+    NF_DYN_LDS(80 * 1024, &gemm_fast_kernel<true>);
     const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
     // few tiles and a long K: split K over enough workgroups to fill the chip (>= 4 k tiles each)
     const int tiles = gx * gy, ktiles = (K + FBK - 1) / FBK;
-    if (tiles <= 128 && ktiles >= 8 && getenv("NF_NO_SPLITK") == nullptr) {
-      static bool attr2 = false;
-      if (!attr2) {
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitk_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr2 = true;
-      }
+    if (tiles <= 128 && ktiles >= 8 && !switches().no_splitk) {
+      NF_DYN_LDS(80 * 1024, &gemm_splitk_kernel);
       int S = std::min((512 + tiles - 1) / tiles, ktiles / 4);
       const int Kc = ((ktiles + S - 1) / S) * FBK;
       S = (K + Kc - 1) / Kc;
@@ -726,12 +715,10 @@ static bool launch_rqs_rows(float* y, float* ld, const float* params, long long 
   const long long nblk = (rows + R - 1) / R;
   const int grid = (int)std::min<long long>(nblk, 65536);
   if (inverse) {
-    static bool a = false;
-    if (!a) { hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 1>), 64 * 1024) != NF_OK) return false;
     hipLaunchKernelGGL((rqs_rows_kernel<K, 1>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
   } else {
-    static bool a = false;
-    if (!a) { hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 0>), 64 * 1024) != NF_OK) return false;
     hipLaunchKernelGGL((rqs_rows_kernel<K, 0>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
   }
   return true;
@@ -817,14 +804,9 @@ static int launch_gemm_rqs(const float* A, int lda, const float* Wk5, const floa
                          RqsConst);
   static const Kernel kernels[2][2] = {{&gemm_rqs_kernel<K, 0, false>, &gemm_rqs_kernel<K, 0, true>},
                                        {&gemm_rqs_kernel<K, 1, false>, &gemm_rqs_kernel<K, 1, true>}};
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < 2; ++b)
-        NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b]),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
-  }
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      NF_DYN_LDS(80 * 1024, kernels[a][b]);
   hipLaunchKernelGGL(kernels[inverse ? 1 : 0][gemm_full_ok(Npad, Kdim) ? 1 : 0], dim3(gx * gy), dim3(256), lds, stream, A,
                      lda, Wk5, bk5, y, ldpart, M, Npad, Kdim, D, par, gx, gy, rc);
   return launch_ld_reduce(ldpart, gx, M, ld, stream);
@@ -1139,7 +1121,7 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   // K5: the last Linear of a spline layer through gemm_rqs_kernel
   k5 = false;
   if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
-  if (d.kind == NF_KIND_RQS_MASKED && getenv("NF_NO_K5") == nullptr &&
+  if (d.kind == NF_KIND_RQS_MASKED && !switches().no_k5 &&
       (d.rqs_bins == 6 || d.rqs_bins == 8 || d.rqs_bins == 10 || d.rqs_bins == 12)) {
     const Linear& last = linears[nlin - 1];
     const int ppb = 128 / P;
@@ -1269,7 +1251,7 @@ int launch_transform(const nf_flow_desc& d, float* yc, float* ldc, const float* 
     hipLaunchKernelGGL(affine_split_kernel, dim3(grid), dim3(256), 0, stream, yc, ldc, params, n, D, par, inverse_op);
   } else {
     bool done = false;
-    if (getenv("NF_RQS_SIMPLE") == nullptr) {
+    if (!switches().rqs_simple) {
       switch (rc.K) {  // the bin counts the register form is built for; others take the run-time-K kernel below
         case 4: done = launch_rqs_rows<4>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
         case 6: done = launch_rqs_rows<6>(yc, ldc, params, n, D, par, inverse_op, rc, stream); break;
@@ -1343,7 +1325,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         // (a batch of one or two row blocks leaves the fused kernel ~80 workgroups that each walk the whole K; the
         // split-K GEMM + the transform kernel are quicker there: 45 -> 32 us per layer at the MNIST shape, batch 128)
         const bool k5_small = (long long)(k5_npad / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
-                              getenv("NF_NO_SPLITK") == nullptr;
+                              !switches().no_splitk;
         if (j == nlin - 1 && k5 && !k5_small && !record_tape && (lda & 3) == 0 &&
             (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
           // K5: GEMM + spline in one kernel; theta stays in LDS
@@ -1371,7 +1353,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         // bf16x3 mode: grids of a few tiles (small batches) take the float32 GEMM, which splits K over the chip
         // (the same test as launch_gemm's)
         const bool few_tiles = (long long)((L.N + 127) / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
-                               getenv("NF_NO_SPLITK") == nullptr;
+                               !switches().no_splitk;
         if (x3 && d_wx3 && !few_tiles && gemm_x3_applicable(a, lda, L.N, L.K))
           NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
                                 j == nlin - 1 ? 0 : act, stream));

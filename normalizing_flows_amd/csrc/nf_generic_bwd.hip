@@ -612,14 +612,10 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
         const int ipp = std::min<int>(256, (int)((size_t)150 * 1024 / ((size_t)2 * P * sizeof(float))));  // K = 32: 197
         const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(4096, (n * Dt + ipp - 1) / ipp)));
         const size_t lds = (size_t)2 * ipp * P * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_masked_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          attr_set = true;
-        }
+        NF_DYN_LDS(160 * 1024, &rqs_masked_bwd_kernel<4>);
+        NF_DYN_LDS(160 * 1024, &rqs_masked_bwd_kernel<8>);
+        NF_DYN_LDS(160 * 1024, &rqs_masked_bwd_kernel<12>);
+        NF_DYN_LDS(160 * 1024, &rqs_masked_bwd_kernel<32>);
         if (rc.K <= 4) hipLaunchKernelGGL((rqs_masked_bwd_kernel<4>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
         else if (rc.K <= 8) hipLaunchKernelGGL((rqs_masked_bwd_kernel<8>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);
         else if (rc.K <= 12) hipLaunchKernelGGL((rqs_masked_bwd_kernel<12>), grid, dim3(256), lds, stream, vc, gc, th, dth, n, D, par, gld, ipp, rc);

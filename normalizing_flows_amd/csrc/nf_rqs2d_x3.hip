@@ -308,12 +308,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void chain_kernel(Params p) {
 template <int T, int WAVES, int INV, int K>
 static int launch_t(const Params& p, int grid, hipStream_t stream) {
   const size_t lds_bytes = 2 * (size_t)kLayerFloats * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    NF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<T, WAVES, INV, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  NF_DYN_LDS(160 * 1024, &chain_kernel<T, WAVES, INV, K>);
   hipLaunchKernelGGL((chain_kernel<T, WAVES, INV, K>), dim3(grid), dim3(WAVES * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;
@@ -341,7 +336,7 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
   p.min_slope = d.rqs_min_knot_slope;
   p.slope_offset = logf(expf(1.f - d.rqs_min_knot_slope) - 1.f);
   int T = 2, waves = 8;  // NF_RQS2D_X3_TUNE="T,WAVES": development knob (measured: profiles/bench_configs.py c)
-  if (const char* e = getenv("NF_RQS2D_X3_TUNE")) sscanf(e, "%d,%d", &T, &waves);
+  if (const int* e = switches().rqs2d_x3_tune; e[0]) { T = e[0]; waves = e[1]; }
   if (waves != 8) { waves = 16; T = 1; }
   if (T != 2) T = 1;
   const int cap = 256;  // one workgroup per CU: two images are 100 KB of LDS

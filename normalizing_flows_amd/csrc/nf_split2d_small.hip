@@ -280,11 +280,11 @@ int launch(const float* wimg, int H, int activation, int first_flip, const Chain
   // (profiles/scratch/sweep_split2d.sh; NF_SPLIT2D_SAMPLES, NF_SPLIT2D_GRID are the development knobs)
   // -- once the batch fills the chip twice over; below that two per lane keep more waves in flight
   int S = io.rows >= (1LL << 22) ? 4 : 2;
-  if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) S = v; }
+  if (switches().split2d_samples) S = switches().split2d_samples;
   const long long groups = (io.rows + S - 1) / S;
   long long want = (groups + 255) / 256;
   int cap = max_grid();
-  if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= kBlockSumCap) cap = v; }
+  if (switches().split2d_grid) cap = switches().split2d_grid;
   const int grid = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   if (out_grid) *out_grid = grid;
   if (S == 8) launch_v<4>(p, wimg, leaky, grid, lds_bytes, stream);

@@ -310,6 +310,39 @@ def test_layer_signature_cache_distinguishes_closures():
     g1.signature()
     g2.signature()
     assert g1._perm == (1, 0) and g2._perm == (1, 0)
+    # NumPy scalars are keyed by VALUE (a fresh np.float32 per rebuild was keyed by its address, which
+    # CPython recycles -- a changed value could land on the old id and silently reuse the old spline range)
+    def make_np(hi):
+        lo, up = np.float32(-hi), np.float32(hi)
+
+        def rqs_fn(p):
+            return distrax.RationalQuadraticSpline(p, range_min=float(lo), range_max=float(up))
+        return distrax.MaskedCoupling(mask, rqs_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    n0 = len(bijectors._SIGNATURES)
+    for hi in (8.0, 5.0, 8.0, 3.0, 5.0) * 20:      # rebuilt over and over, as haiku_like's apply does
+        assert make_np(hi).signature().rqs[1:3] == (-hi, hi)
+    assert len(bijectors._SIGNATURES) == n0 + 3
+    # identity-keyed objects are held by the cache entry (their ids cannot be recycled while it lives) ...
+    assert all(len(v) == 3 and any(o is distrax for o in v[2]) for k, v in bijectors._SIGNATURES.items())
+    # ... a module global the function reads is part of the key ...
+    g = {"distrax": distrax, "HI": 8.0}
+    exec("def glob_fn(p):\n    return distrax.RationalQuadraticSpline(p, range_min=-HI, range_max=HI)\n", g)
+    mk = lambda: distrax.MaskedCoupling(mask, g["glob_fn"], distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))  # noqa: E731
+    assert mk().signature().rqs[2] == 8.0
+    g["HI"] = 2.0
+    assert mk().signature().rqs[2] == 2.0
+    # ... and any other captured object makes the layer uncacheable instead of being keyed by its address
+    class Cfg:
+        hi = 8.0
+    cfg = Cfg()
+
+    def cfg_fn(p):
+        return distrax.RationalQuadraticSpline(p, range_min=-cfg.hi, range_max=cfg.hi)
+    h1 = distrax.MaskedCoupling(mask, cfg_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    assert h1._signature_cache_key() is None and h1.signature().rqs[2] == 8.0
+    cfg.hi = 7.0
+    h2 = distrax.MaskedCoupling(mask, cfg_fn, distrax.make_conditioner((2,), [64, 64], 37, per_dim=True))
+    assert h2.signature().rqs[2] == 7.0
 
 
 def test_lowering_recognises_reference_structures_without_a_gpu():
@@ -369,6 +402,42 @@ def test_lowering_recognises_reference_structures_without_a_gpu():
     assert _seed_u64(7) == 7 and _seed_u64(np.array([1, 2], np.uint32)) == (0x9E3779B97F4A7C15 + 2) % 2 ** 64
     with pytest.raises(ValueError):
         distrax.Transformed(distrax.Normal(0.0, 1.0), chain)
+
+
+@pytest.mark.parametrize("mode", ["ok", "fail", "hang"])
+def test_bench_spawns_its_own_ranks(tmp_path, mode):
+    """`python bench.py --gpus N` as typed (WORLD_SIZE unset): the parent starts N rank processes with the launcher's
+    environment, relays rank 0's line when all succeed, and ends everybody + exits non-zero when one rank fails or the
+    limit passes (the ranks here are tests/_bench_stub_worker.py -- no GPU, no library)."""
+    import json
+    import time
+    root, HERE = ROOT, os.path.join(ROOT, "tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NF_BENCH_WORKER=os.path.join(HERE, "_bench_stub_worker.py"), NF_STUB_DIR=str(tmp_path), NF_STUB_MODE=mode,
+               NF_BENCH_SPAWN_TIMEOUT="2" if mode == "hang" else "60")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "7", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    recs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(3)]
+    assert [rec["RANK"] for rec in recs] == ["0", "1", "2"] and [rec["LOCAL_RANK"] for rec in recs] == ["0", "1", "2"]
+    assert all(rec["WORLD_SIZE"] == "3" and rec["MASTER_ADDR"] == "127.0.0.1" for rec in recs)
+    assert len({rec["MASTER_PORT"] for rec in recs}) == 1 and int(recs[0]["MASTER_PORT"]) > 0
+    assert all(rec["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for rec in recs)
+    assert all(rec["argv"] == ["--gpus", "3", "--steps", "7", "--warmup", "2"] for rec in recs)
+    assert len({rec["sid"] for rec in recs}) == 3 and all(rec["sid"] == rec["pid"] for rec in recs)  # own groups
+    if mode == "ok":
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip().splitlines() == [json.dumps({"metric": "stub", "n_gpus": 3})]
+        assert "rank 1 chatter" in r.stderr
+    else:
+        assert r.returncode == (3 if mode == "fail" else 124), (r.returncode, r.stderr)
+        assert r.stdout == ""                       # no result line, not even rank 0's partial output
+        assert took < 30                            # nobody waited for the sleepers
+        assert ("rank 1 of 3 exited with 3" in r.stderr) if mode == "fail" else ("still running" in r.stderr)
+    for rec in recs:                                # every rank process is gone either way
+        with pytest.raises(ProcessLookupError):
+            os.kill(rec["pid"], 0)
 
 
 def test_shard_rows():

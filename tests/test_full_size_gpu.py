@@ -308,29 +308,31 @@ def test_large_host_buffer_calls_are_pipelined_with_the_same_bits(nfa, monkeypat
     if kind == "affine":
         spec = O.make_affine_spec(8, final_std=0.03)
         cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=8, hidden=(64, 64))
-        f = nfa.CouplingFlow(cfg, spec.layers)
+        layers = spec.layers
     elif kind == "rqs":
         spec = O.make_rqs_spec(4, final_std=0.05)
         cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=2, num_layers=4, hidden=(64, 64), rqs_bins=12,
                              rqs_range_min=-8.0, rqs_range_max=8.0)
-        f = nfa.CouplingFlow(cfg, spec.layers)
+        layers = spec.layers
     else:
         params, flips = O.make_a_params(8)
         cfg = nfa.FlowConfig(kind=_lib.KIND_AFFINE_SPLIT, event_dim=2, num_layers=8, hidden=(4,),
                              activation=_lib.ACT_LEAKY_RELU, first_mask_parity=0)
-        f = nfa.CouplingFlow(cfg, [[(W, b) for W, b in net] for net in params])
+        layers = [[(W, b) for W, b in net] for net in params]
+    f = nfa.CouplingFlow(cfg, layers)
     rows = (1 << 20) + 12345
     x = O.make_inputs("banana", rows, seed=3)
     lib = _lib.load()
 
-    def sample(seed):
+    def sample(seed, h=None):
         out = np.empty((rows, 2), np.float32)
-        _lib.check(lib.nf_sample(f._h, C.c_uint64(seed), rows, out.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+        _lib.check(lib.nf_sample((h or f)._h, C.c_uint64(seed), rows, out.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
         return out
     lp_piped, s_piped = f.log_prob(x), sample(11)
-    monkeypatch.setenv("NF_NO_HOST_PIPELINE", "1")
-    lp_plain, s_plain = f.log_prob(x), sample(11)
+    monkeypatch.setenv("NF_NO_HOST_PIPELINE", "1")   # switches are read when a handle is created
+    g = nfa.CouplingFlow(cfg, layers)
     monkeypatch.delenv("NF_NO_HOST_PIPELINE")
+    lp_plain, s_plain = g.log_prob(x), sample(11, g)
     assert np.array_equal(lp_piped, lp_plain) and np.isfinite(lp_piped).all()
     assert np.array_equal(s_piped, s_plain)
     assert not np.array_equal(s_piped, sample(12))

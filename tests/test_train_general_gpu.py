@@ -401,6 +401,28 @@ def test_skip_nonfinite_updates(nfa, kind):
     t.train_step(b3, opt)
     wp, wt = _flat(plain.get_weights()), _flat(t.get_weights())
     assert np.abs(wt - wp).max() <= 2e-6 * max(1.0, np.abs(wp).max()), np.abs(wt - wp).max()
+    # set_weights on a trained handle restarts the optimiser -- moments, host count AND the device-side count of applied
+    # steps the option keeps: five steps, new weights, two more steps == a fresh handle's two steps (left at t = 5 the
+    # bias correction would make the first step after the restart ~3x too large)
+    r = make()
+    r.set_option("skip_nonfinite_updates", "1")
+    for xb in (good, b2, b3, good, b2):
+        r.train_step(xb, opt)
+    r.set_weights(spec.layers)
+    fresh = make()
+    fresh.set_option("skip_nonfinite_updates", "1")
+    for xb in (b3, good):
+        r.train_step(xb, opt)
+        fresh.train_step(xb, opt)
+    wr, wf = _flat(r.get_weights()), _flat(fresh.get_weights())
+    assert np.abs(wr - wf).max() <= 1e-7 * max(1.0, np.abs(wf).max()), np.abs(wr - wf).max()
+    # ... and switching the option off afterwards hands over the restarted count, not the old one
+    r.set_option("skip_nonfinite_updates", "0")
+    fresh.set_option("skip_nonfinite_updates", "0")
+    r.train_step(b2, opt)
+    fresh.train_step(b2, opt)
+    wr, wf = _flat(r.get_weights()), _flat(fresh.get_weights())
+    assert np.abs(wr - wf).max() <= 1e-7 * max(1.0, np.abs(wf).max()), np.abs(wr - wf).max()
 
 
 @pytest.mark.parametrize("K", [21, 32])
