@@ -121,6 +121,31 @@ def cpu_baseline(layers, layers4, density):
                  "value": rows * reps_np / dt_np, "unit": "evals/s", "cores": usable_cpus(), "calls": reps_np}]}
 
 
+def parity_check(kind, layers, x, got, rqs=None):
+    """The ACHIEVED error of the measured kernel, for the record: `got` = the log_prob values the timed steps left in
+    HBM for the first rows of the resident batch, against the float64 oracle on the same rows and weights (outside the
+    timed region; the oracle is the checker, never the thing measured -- with cpu_baseline() the only place this file
+    touches oracle/).  scaled = |got - ref| / max(1, |ref|), the tolerance of every parity test (DESIGN.md 7);
+    max_abs_where_ref_le_8: the largest ABSOLUTE error over rows with |ref| <= 8 (north_star's literal 1e-5)."""
+    from oracle import flows_np as O
+    if kind == "affine":
+        ref = O.log_prob(O.FlowSpec("affine", 2, layers, O.alternating_masks(2, len(layers), 1)), x)
+    elif kind == "rqs":
+        ref = O.log_prob(O.FlowSpec("rqs", 2, layers, O.alternating_masks(2, len(layers), 1), "normal", rqs[0], rqs[1],
+                                    rqs[2]), x)
+    else:  # the flow of src/real_nvp.py: params[layer] = [[W, b], [W, b]], flips F, T, F, T ...
+        ref = O.a_log_prob_chain([[(W, b) for W, b in net] for net in layers], [bool(l & 1) for l in range(len(layers))], x)
+    got = np.asarray(got, np.float64)
+    err = np.abs(got - ref)
+    scaled = err / np.maximum(1.0, np.abs(ref))
+    small = np.abs(ref) <= 8.0
+    return {"rows": int(len(ref)), "against": "oracle/flows_np.py float64 (parity unpinned: DESIGN.md 1c)",
+            "max_scaled": float(scaled.max()), "rms_scaled": float(np.sqrt((scaled ** 2).mean())),
+            "outside_1e-5": int((scaled > 1e-5).sum()), "rows_abs_ref_le_8": int(small.sum()),
+            "max_abs_where_ref_le_8": float(err[small].max()) if small.any() else None,
+            "tolerance": "1e-5 * max(1, |ref|)"}
+
+
 def spawn_ranks(n, argv, worker=None, timeout_s=None):
     """`python bench.py --gpus N` typed as it stands (no launcher, WORLD_SIZE unset, N > 1): this process becomes the
     PARENT of N fresh rank processes and never touches the GPU itself -- nothing of libnf_hip, HIP or torch is loaded
@@ -320,6 +345,8 @@ def main():
         return wall, ev_ms, walls, result
 
     wall, ev_ms, walls, nll = headline_run()
+    # what the timed steps left in HBM for the first 4096 rows (checked against the oracle after the measurements)
+    parity_rows = (xd.rows(0, 4096).to_numpy(), lpd.rows(0, 4096).to_numpy()) if rank == 0 and world == 1 and rows >= 4096 else None
     variant = None
     if args.hidden_matmul == "f32" and not args.no_variants:
         # the same steps once more under the optional split-bf16 hidden matmul (same tolerance
@@ -394,6 +421,11 @@ def main():
                                     "frac": mfma_flop / kern_s / 1e12 / 2500.0,
                                     "note": "bf16 MFMA FLOP issued (6 terms) vs dense bf16 peak; the float32-"
                                             f"equivalent rate is {achieved_tflops:.1f} TFLOP/s"})
+        if world == 1 and not args.no_cpu_baseline and parity_rows is not None:
+            try:
+                out["parity"] = parity_check("affine", layers, parity_rows[0], parity_rows[1])
+            except Exception as exc:  # noqa: BLE001
+                out.setdefault("side_errors", []).append(f"parity: {type(exc).__name__}: {exc}")
         if variant is not None:
             out["variants"] = [variant]
         if other:
@@ -425,7 +457,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
     each with its useful-FLOP roofline.  Synthetic weights of the architecture, inputs resident in HBM."""
     res = []
 
-    def run(name, cfg, layers, xd, rows, steps, flop_per_eval, note, dominant=None, hbm_bound=False):
+    def run(name, cfg, layers, xd, rows, steps, flop_per_eval, note, dominant=None, hbm_bound=False, parity=None):
         f = flow.CouplingFlow(cfg, layers)
         lpd = flow.DeviceArray((rows,))
         step = lambda i: f.nll_enqueue(xd, rows, i % _lib.NF_NLL_SLOTS, lpd)  # noqa: E731
@@ -447,6 +479,13 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
             traffic, src = profiled_traffic(*dominant)
             res[-1]["roofline"].update({"traffic": traffic, "traffic_unit": f"bytes of HBM per launch of {dominant[0]} "
                                                                             f"(rocprofv3 PMC, {src})"})
+        if parity is not None and not args.no_cpu_baseline:
+            try:
+                n = min(rows, 4096)
+                res[-1]["parity"] = parity_check(parity[0], layers, xd.rows(0, n).to_numpy(), lpd.rows(0, n).to_numpy(),
+                                                 parity[1] if len(parity) > 1 else None)
+            except Exception as exc:  # noqa: BLE001
+                res[-1]["parity_error"] = f"{type(exc).__name__}: {exc}"
         f.close()
 
     # configs[0]: 4 affine layers, banana, 4096 rows (the reference's CPU-runnable case; latency-bound on a GPU)
@@ -455,7 +494,8 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
     cfg = flow.FlowConfig(kind=_lib.KIND_AFFINE_MASKED, event_dim=2, num_layers=4, hidden=(64, 64))
     xd = next(densities.get_density("banana")(seed=2123, batch_size=4096, num_batches=1, device=True))
     run("configs[0]: RealNVP 4 affine layers, banana, batch=4096", cfg, layers, xd, 4096, max(args.steps, 200),
-        4 * FLOP_AFFINE_PER_LAYER, "16 of the chip's 1024 SIMDs hold a tile: latency-bound, not a roofline case")
+        4 * FLOP_AFFINE_PER_LAYER, "16 of the chip's 1024 SIMDs hold a tile: latency-bound, not a roofline case",
+        parity=("affine",))
     # configs[2]: spline coupling ("MAF" in the reference), 8 layers, K = 12 on [-8, 8], gaussian_blobs, 2^20 rows
     layers = [make_conditioner((2,), [64, 64], 37, per_dim=True, rng=np.random.default_rng(534 + l),
                                final_std=0.05).linears for l in range(8)]
@@ -466,7 +506,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
         xd, 1 << 20, args.steps, 8 * FLOP_RQS12_PER_LAYER,
         "useful FLOP = the 37 spline parameters of the transformed dim; the kernel computes 26 of them on the MFMA "
         "and the 2 slope logits of the sample's bin on the VALU",
-        dominant=("void nf::rqs2d::chain_kernel", "config_c_pmc_summary.json"))
+        dominant=("void nf::rqs2d::chain_kernel", "config_c_pmc_summary.json"), parity=("rqs", (12, -8.0, 8.0)))
     del xd
     # the flow of src/real_nvp.py (north_star's other drop-in script; not a BASELINE.json config): split halves + flip,
     # MLP 1-4-2 with leaky relu, 8 layers, 2^24 rows -- 12 FMA per sample and layer, no matrix work
@@ -480,7 +520,7 @@ def other_configs(args, lib, _lib, flow, densities, make_conditioner, measure, b
         args.steps, 8 * 2 * (4 + 8),
         "vector-issue bound: 17 instructions per sample and layer (activation as alpha a + beta |a|: three fma per hidden "
         "unit), counters in profiles/r03/config_a_pmc_summary.json; HBM moves 12 B per eval", dominant=("void nf::split2d::chain_kernel", "config_a_pmc_summary.json"),
-        hbm_bound=True)
+        hbm_bound=True, parity=("split",))
     del xd
     # configs[4]: MNIST shape, 6 layers, 784-D, MLP 512x3, K = 8 on [0, 1], Uniform base, 2^16 rows
     layers = [make_conditioner((784,), [512, 512, 512], 25, per_dim=True, rng=np.random.default_rng(534 + l),

@@ -125,9 +125,10 @@ int nf_flow_weight_count(const nf_flow_desc* desc, size_t* out_count);
 /* Replaces make_flow_model (src/real_nvp_toy_densities.py:74-110,
    src/maf_toy_densities.py:74-111, src/maf_mnist.py:52-89) and init_nvp_chain's
    structure (src/real_nvp.py:198-220): builds the chain on the current device.
-   Kernel choice is by shape: 2-D masked flows with two relu hidden layers of at most 64 units
-   (the scripts default to --hidden_size 50, src/real_nvp_toy_densities.py:249-251) run on the fused
-   64/64 kernels -- narrower layers are completed with zero-weight units inside the handle, every
+   Kernel choice is by shape: 2-D masked flows with two relu hidden layers of at most 64 units run on the
+   fused 64/64 kernels (every run of the reference uses 64/64: its command-line flags are parsed but never
+   passed to main, src/real_nvp_toy_densities.py:236-253 vs :284-291, so the module constants :34-36 decide)
+   -- narrower layers are completed with zero-weight units inside the handle, every
    weight / gradient vector that crosses this ABI keeps the layout `desc` describes (environment
    NF_NO_PAD=1: keep such flows on the general path); other shapes take the general path. */
 int nf_flow_create(const nf_flow_desc* desc, nf_flow** out_flow);
@@ -221,6 +222,30 @@ int nf_density_sample(int density, uint64_t seed, int64_t rows, float* out, int 
    output may be NULL. */
 int nf_chain_apply(nf_flow* flow, int direction, int layer_begin, int layer_end,
                    const float* x, int64_t rows, float* y, float* logdet, int mem);
+
+/* Replaces the stand-alone evaluation of the INNER (element-wise, event_ndims_in = 0) bijectors the coupling layers
+   are built from -- `forward_and_log_det` / `inverse_and_log_det` of the distrax.Bijector protocol
+   (README.md:32-57) for distrax.ScalarAffine(shift, log_scale | scale) (src/real_nvp_toy_densities.py:86) and
+   distrax.RationalQuadraticSpline(params, range_min, range_max) (src/maf_toy_densities.py:87, src/maf_mnist.py:66)
+   -- on explicit parameter arrays: element e of x[n] is mapped with ITS OWN parameters,
+     NF_ELEM_AFFINE_LOG_SCALE  params[n][2] = (shift, log_scale):  y = exp(log_scale) x + shift, logdet = log_scale
+     NF_ELEM_AFFINE_SCALE      params[n][2] = (shift, scale):      y = scale x + shift,          logdet = log|scale|
+     NF_ELEM_RQS               params[n][3K+1] (widths K | heights K | slopes K+1): the spline of nf_kind
+                               NF_KIND_RQS_MASKED (same arithmetic, same kernels), linear tails outside the range,
+   inverse != 0: the inverse map and ITS log-determinant (= minus the forward one at the preimage).
+   out_y[n], out_logdet[n]; either may be NULL.  No handle: runs on the default stream and has completed on return.
+   (Broadcasting shift / log_scale / params against x, as distrax does, is the caller's job:
+   normalizing_flows_amd/bijectors.py materialises the broadcast arrays.) */
+typedef enum nf_elementwise_kind { NF_ELEM_AFFINE_LOG_SCALE = 0, NF_ELEM_AFFINE_SCALE = 1, NF_ELEM_RQS = 2 } nf_elementwise_kind;
+typedef struct nf_elementwise_desc {
+  int32_t abi_version;             /* NF_ABI_VERSION */
+  int32_t kind;                    /* nf_elementwise_kind */
+  int32_t rqs_bins;                /* K (NF_ELEM_RQS only) */
+  float rqs_range_min, rqs_range_max;
+  float rqs_min_bin_size, rqs_min_knot_slope; /* distrax defaults 1e-4, 1e-4 */
+} nf_elementwise_desc;
+int nf_elementwise_apply(const nf_elementwise_desc* desc, int inverse, const float* x, const float* params,
+                         int64_t n, float* out_y, float* out_logdet, int mem);
 
 /* Replaces loss_fn / eval_fn: -mean(log_prob) (src/real_nvp_toy_densities.py:139-151,
    src/real_nvp.py:292-293).  Sums log_prob over the local rows in float64 in a

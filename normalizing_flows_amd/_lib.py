@@ -67,6 +67,22 @@ class FlowDesc(C.Structure):
     ]
 
 
+# nf_elementwise_kind
+ELEM_AFFINE_LOG_SCALE, ELEM_AFFINE_SCALE, ELEM_RQS = 0, 1, 2
+
+
+class ElementwiseDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("kind", C.c_int32),
+        ("rqs_bins", C.c_int32),
+        ("rqs_range_min", C.c_float),
+        ("rqs_range_max", C.c_float),
+        ("rqs_min_bin_size", C.c_float),
+        ("rqs_min_knot_slope", C.c_float),
+    ]
+
+
 _c_float_p = C.POINTER(C.c_float)
 _void_pp = C.POINTER(C.c_void_p)
 
@@ -94,6 +110,8 @@ PROTOTYPES = {
     "nf_log_prob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_chain_log_prob": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "nf_base_log_prob": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "nf_elementwise_apply": (C.c_int, [C.POINTER(ElementwiseDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_int]),
     "nf_base_sample": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),
     "nf_density_sample": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),
     "nf_sample": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_int]),

@@ -76,33 +76,61 @@ class Bijector:
 # --------------------------------------------------------------------------
 # inner (element-wise) bijectors: descriptions the coupling layer is built from
 # --------------------------------------------------------------------------
+def _elementwise(desc: "_lib.ElementwiseDesc", inverse: bool, x, params: np.ndarray):
+    """x (any shape) and params (x.shape + (P,)) through nf_elementwise_apply; returns (y, logdet), each of x's
+    shape.  Host arrays in, host arrays out (the parameters of a stand-alone inner bijector are host arrays)."""
+    import ctypes as C
+    x = np.asarray(x, np.float32)
+    P = params.shape[-1]
+    shape = np.broadcast_shapes(x.shape, params.shape[:-1])
+    xb = np.ascontiguousarray(np.broadcast_to(x, shape))
+    pb = np.ascontiguousarray(np.broadcast_to(params, shape + (P,)), np.float32)
+    y = np.empty(shape, np.float32)
+    ld = np.empty(shape, np.float32)
+    _lib.check(_lib.load().nf_elementwise_apply(C.byref(desc), 1 if inverse else 0, xb.ctypes.data_as(C.c_void_p),
+                                                pb.ctypes.data_as(C.c_void_p), xb.size, y.ctypes.data_as(C.c_void_p),
+                                                ld.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+    return y, ld
+
+
 class ScalarAffine(Bijector):
-    """y = exp(log_scale) * x + shift (distrax.ScalarAffine; used at
-    src/real_nvp_toy_densities.py:86).  Inside `MaskedCoupling` its parameters come
-    from the conditioner and the map is evaluated by the fused kernel."""
+    """y = scale * x + shift with scale = exp(log_scale) (distrax.ScalarAffine; used at
+    src/real_nvp_toy_densities.py:86).  Inside `MaskedCoupling` its parameters come from the conditioner and the
+    map is evaluated by the fused kernel; on its own (explicit `shift` and `log_scale` or `scale` arrays, broadcast
+    against the input as distrax does) it runs through nf_elementwise_apply."""
 
     def __init__(self, shift, scale=None, log_scale=None):
         super().__init__(event_ndims_in=0, is_constant_jacobian=True)
         if scale is not None and log_scale is not None:
             raise ValueError("only one of scale and log_scale may be given")
-        if scale is not None:
-            raise NotImplementedError("the HIP path parameterises the affine map by log_scale only")
         self.shift = shift
-        self.log_scale = log_scale if log_scale is not None else np.zeros_like(np.asarray(shift))
+        if scale is not None:
+            self.scale = scale
+            self.log_scale = None       # distrax derives log|scale| lazily; the kernel does (NF_ELEM_AFFINE_SCALE)
+        else:
+            self.scale = None
+            self.log_scale = log_scale if log_scale is not None else np.zeros_like(np.asarray(shift))
 
-    def _unfused(self, *_):
-        raise NotImplementedError(
-            "stand-alone ScalarAffine evaluation is off the accelerated path; use it as the "
-            "inner bijector of MaskedCoupling (no CPU fallback)")
+    def _apply(self, v, inverse: bool):
+        second = self.log_scale if self.scale is None else self.scale
+        shift, second = np.broadcast_arrays(np.asarray(self.shift, np.float32), np.asarray(second, np.float32))
+        desc = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION,
+                                    kind=_lib.ELEM_AFFINE_LOG_SCALE if self.scale is None else _lib.ELEM_AFFINE_SCALE)
+        return _elementwise(desc, inverse, v, np.stack([shift, second], axis=-1))
 
-    forward_and_log_det = _unfused
-    inverse_and_log_det = _unfused
+    def forward_and_log_det(self, x):
+        return self._apply(x, False)
+
+    def inverse_and_log_det(self, y):
+        return self._apply(y, True)
 
 
 class RationalQuadraticSpline(Bijector):
     """distrax.RationalQuadraticSpline (used at src/maf_toy_densities.py:86-87 and
     src/maf_mnist.py:65-66): monotone rational-quadratic spline on
-    [range_min, range_max] with linear tails; `params[..., 3K+1]`."""
+    [range_min, range_max] with linear tails; `params[..., 3K+1]`.  Inside `MaskedCoupling` the fused kernels
+    evaluate it; on its own (explicit `params`, batch dimensions broadcast against the input) it runs through
+    nf_elementwise_apply -- the same spline arithmetic (csrc/nf_rqs_math.h)."""
 
     def __init__(self, params, range_min: float, range_max: float,
                  boundary_slopes: str = "unconstrained", min_bin_size: float = 1e-4,
@@ -126,13 +154,17 @@ class RationalQuadraticSpline(Bijector):
         self.min_bin_size = float(min_bin_size)
         self.min_knot_slope = float(min_knot_slope)
 
-    def _unfused(self, *_):
-        raise NotImplementedError(
-            "stand-alone RationalQuadraticSpline evaluation is off the accelerated path; use it "
-            "as the inner bijector of MaskedCoupling (no CPU fallback)")
+    def _apply(self, v, inverse: bool):
+        desc = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION, kind=_lib.ELEM_RQS, rqs_bins=self.num_bins,
+                                    rqs_range_min=self.range_min, rqs_range_max=self.range_max,
+                                    rqs_min_bin_size=self.min_bin_size, rqs_min_knot_slope=self.min_knot_slope)
+        return _elementwise(desc, inverse, v, np.asarray(self.params, np.float32))
 
-    forward_and_log_det = _unfused
-    inverse_and_log_det = _unfused
+    def forward_and_log_det(self, x):
+        return self._apply(x, False)
+
+    def inverse_and_log_det(self, y):
+        return self._apply(y, True)
 
 
 # --------------------------------------------------------------------------
@@ -321,6 +353,9 @@ class MaskedCoupling(Bijector):
             if n_out != 2 or cond.params_per_dim is not None:
                 raise NotImplementedError("the affine kernel takes exactly 2 conditioner outputs "
                                           "(shift, log_scale) broadcast over the event")
+            if inner_a.log_scale is None or inner_b.log_scale is None:
+                raise NotImplementedError("inside MaskedCoupling the affine kernels take ScalarAffine(shift, log_scale); "
+                                          "the scale= form is evaluated stand-alone only")
             perm = None
             for cand in ((0, 1), (1, 0)):
                 ok = True

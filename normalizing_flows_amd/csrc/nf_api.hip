@@ -1144,6 +1144,86 @@ int nf_base_log_prob(int base, int event_dim, const float* x, int64_t rows, floa
   return s;
 }
 
+int nf_elementwise_apply(const nf_elementwise_desc* desc, int inverse, const float* x, const float* params,
+                         int64_t n, float* out_y, float* out_logdet, int mem) {
+  if (!desc) { set_error("desc is NULL"); return NF_ERR_INVALID; }
+  if (desc->abi_version != NF_ABI_VERSION) {
+    set_error("desc.abi_version %d, library speaks %d", desc->abi_version, NF_ABI_VERSION); return NF_ERR_INVALID;
+  }
+  if (desc->kind < NF_ELEM_AFFINE_LOG_SCALE || desc->kind > NF_ELEM_RQS) {
+    set_error("unknown element-wise bijector kind %d", desc->kind); return NF_ERR_INVALID;
+  }
+  if (n < 0) { set_error("n must be >= 0"); return NF_ERR_INVALID; }
+  if (mem != NF_MEM_HOST && mem != NF_MEM_DEVICE) { set_error("unknown mem %d", mem); return NF_ERR_INVALID; }
+  nf_flow_desc fd;
+  memset(&fd, 0, sizeof(fd));
+  int P = 2;
+  if (desc->kind == NF_ELEM_RQS) {
+    // the spline is the coupling kinds' own: a "flow" of event size 1 whose single dim is the transformed one
+    fd.abi_version = NF_ABI_VERSION;
+    fd.kind = NF_KIND_RQS_MASKED;
+    fd.event_dim = 2;   // (validate_desc wants >= 2; the transform below is told D = 1)
+    fd.num_layers = 1; fd.num_hidden = 1; fd.hidden[0] = 1;
+    fd.activation = NF_ACT_RELU; fd.base = NF_BASE_STD_NORMAL; fd.first_mask_parity = 1;
+    fd.rqs_bins = desc->rqs_bins; fd.rqs_range_min = desc->rqs_range_min; fd.rqs_range_max = desc->rqs_range_max;
+    fd.rqs_min_bin_size = desc->rqs_min_bin_size; fd.rqs_min_knot_slope = desc->rqs_min_knot_slope;
+    NF_TRY(validate_desc(&fd));   // the checks distrax.RationalQuadraticSpline makes in its constructor
+    fd.event_dim = 1;
+    P = 3 * desc->rqs_bins + 1;
+  }
+  if (n == 0) return NF_OK;
+  if (!x || !params) { set_error("x or params is NULL"); return NF_ERR_INVALID; }
+  if (!out_y && !out_logdet) return NF_OK;
+  int ndev = 0;
+  nf_device_count(&ndev);
+  if (ndev == 0) { set_error("no HIP device visible: libnf_hip has no CPU fallback"); return NF_ERR_NO_DEVICE; }
+  const Switches sw_now = Switches::from_env();
+  UseSwitches use_sw(&sw_now);
+  const bool host = mem == NF_MEM_HOST;
+  const size_t nb = sizeof(float) * (size_t)n;
+  // device buffers: x, params (staged from the host, or the caller's), y and logdet (the spline kernels update
+  // y in place and ADD to logdet, so both always exist on the device here)
+  float *dx = nullptr, *dp = nullptr, *dy = nullptr, *dl = nullptr;
+  bool own_y = false, own_l = false;
+  int s = NF_OK;
+  hipError_t e = hipSuccess;
+  auto fail = [&](const char* what) { s = hip_fail(e, what, __FILE__, __LINE__); };
+  do {
+    if (host) {
+      if ((e = hipMalloc(&dx, nb)) != hipSuccess || (e = hipMalloc(&dp, nb * P)) != hipSuccess) { fail("hipMalloc"); break; }
+      if ((e = hipMemcpy(dx, x, nb, hipMemcpyHostToDevice)) != hipSuccess ||
+          (e = hipMemcpy(dp, params, nb * P, hipMemcpyHostToDevice)) != hipSuccess) { fail("hipMemcpy"); break; }
+    } else {
+      NF_HIP(hipDeviceSynchronize());  // x / params may have been produced on a handle's (non-blocking) stream
+    }
+    const float* cx = host ? dx : x;
+    const float* cp = host ? dp : params;
+    const bool rqs = desc->kind == NF_ELEM_RQS;
+    if (host || (rqs && !out_y)) { if ((e = hipMalloc(&dy, nb)) != hipSuccess) { fail("hipMalloc"); break; } own_y = true; }
+    else dy = out_y;
+    if (host || (rqs && !out_logdet)) { if ((e = hipMalloc(&dl, nb)) != hipSuccess) { fail("hipMalloc"); break; } own_l = true; }
+    else dl = out_logdet;
+    if (rqs) {
+      if ((e = hipMemcpyAsync(dy, cx, nb, hipMemcpyDeviceToDevice, nullptr)) != hipSuccess ||
+          (e = hipMemsetAsync(dl, 0, nb, nullptr)) != hipSuccess) { fail("hipMemcpyAsync"); break; }
+      s = generic::launch_transform(fd, dy, dl, cp, n, /*par=*/1, inverse ? 1 : 0, generic::make_rqs_const(fd), nullptr);
+    } else {
+      s = generic::launch_scalar_affine(cx, cp, dy, dl, n, inverse ? 1 : 0, desc->kind == NF_ELEM_AFFINE_SCALE, nullptr);
+    }
+    if (s != NF_OK) break;
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) { fail("hipStreamSynchronize"); break; }
+    if (host) {
+      if (out_y && (e = hipMemcpy(out_y, dy, nb, hipMemcpyDeviceToHost)) != hipSuccess) { fail("hipMemcpy"); break; }
+      if (out_logdet && (e = hipMemcpy(out_logdet, dl, nb, hipMemcpyDeviceToHost)) != hipSuccess) { fail("hipMemcpy"); break; }
+    }
+  } while (0);
+  hipFree(dx);
+  hipFree(dp);
+  if (own_y) hipFree(dy);
+  if (own_l) hipFree(dl);
+  return s;
+}
+
 int nf_base_sample(int base, int event_dim, uint64_t seed, int64_t rows, float* out, int mem) {
   if (base != NF_BASE_STD_NORMAL && base != NF_BASE_UNIFORM01) { set_error("unknown base %d", base); return NF_ERR_INVALID; }
   if (event_dim < 1 || rows < 0) { set_error("bad shape"); return NF_ERR_INVALID; }

@@ -565,6 +565,35 @@ __global__ __launch_bounds__(256) void affine_masked_kernel(float* __restrict__ 
   }
 }
 
+// stand-alone distrax.ScalarAffine on explicit parameters: params[n][2] = (shift, log_scale) or (shift, scale)
+__global__ __launch_bounds__(256) void scalar_affine_kernel(const float* __restrict__ x, const float2* __restrict__ params,
+                                                           float* __restrict__ y, float* __restrict__ ld, long long n,
+                                                           int inverse, int params_are_scale) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const float2 p = params[e];
+    const float v = x[e];
+    float out, l;
+    if (params_are_scale) {           // y = scale x + shift, log|det| = log|scale| (distrax takes log(abs(scale)))
+      out = inverse ? (v - p.x) / p.y : fmaf(v, p.y, p.x);
+      l = logf(fabsf(p.y));
+    } else {                          // the coupling kernels' form: exp(log_scale)
+      out = inverse ? (v - p.x) * expf(-p.y) : fmaf(v, expf(p.y), p.x);
+      l = p.y;
+    }
+    if (y) y[e] = out;
+    if (ld) ld[e] = inverse ? -l : l;
+  }
+}
+
+int launch_scalar_affine(const float* x, const float* params, float* y, float* ld, long long n, int inverse,
+                         int params_are_scale, hipStream_t stream) {
+  const int grid = (int)std::max<long long>(1, std::min<long long>(8192, (n + 255) / 256));
+  hipLaunchKernelGGL(scalar_affine_kernel, dim3(grid), dim3(256), 0, stream, x, reinterpret_cast<const float2*>(params), y,
+                     ld, n, inverse, params_are_scale);
+  NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
 // split halves (variant A, any even D): params[rows][D] = (shift[d] | log_scale[d]);
 // flip = 0 transforms the second half conditioned on the first.
 __global__ __launch_bounds__(256) void affine_split_kernel(float* __restrict__ y, float* __restrict__ ld,

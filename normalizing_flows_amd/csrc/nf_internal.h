@@ -237,6 +237,9 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
                 int act, hipStream_t stream, const float* aux = nullptr);
 int launch_transform(const nf_flow_desc& d, float* y, float* ld, const float* params, long long n, int par,
                      int inverse_op, const RqsConst& rc, hipStream_t stream);
+// stand-alone ScalarAffine on explicit per-element parameters (nf_elementwise_apply); y / ld may be null
+int launch_scalar_affine(const float* x, const float* params, float* y, float* ld, long long n, int inverse,
+                         int params_are_scale, hipStream_t stream);
 
 struct Plan {
   nf_flow_desc desc;

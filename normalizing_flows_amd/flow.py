@@ -140,6 +140,11 @@ class DeviceView:
         row = int(np.prod(base.shape[1:])) if len(base.shape) > 1 else 1
         self.ptr = C.c_void_p(base.ptr.value + begin * row * 4)
 
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, np.float32)
+        check(_lib.load().nf_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out
+
 
 ArrayLike = Union[np.ndarray, DeviceArray, DeviceView]
 

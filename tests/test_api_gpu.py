@@ -156,8 +156,15 @@ def test_unsupported_structures_fail_loudly(distrax):
     layer = distrax.MaskedCoupling(mask=mask, bijector=tanh_fn, conditioner=cond)
     with pytest.raises(NotImplementedError):
         layer.forward_and_log_det(np.zeros((4, 2), np.float32))
+    # (stand-alone inner bijectors evaluate since round 4: test_standalone_inner_bijectors)
+    y0, l0 = distrax.ScalarAffine(shift=0.0, log_scale=0.0).forward_and_log_det(np.zeros(3))
+    assert y0.shape == (3,) and np.all(y0 == 0) and np.all(l0 == 0)
+
+    def scale_fn(params):   # the scale= form has no coupling kernel (the reference uses log_scale)
+        shift, scale = np.split(params, 2, axis=-1)
+        return distrax.ScalarAffine(shift=shift, scale=scale)
     with pytest.raises(NotImplementedError):
-        distrax.ScalarAffine(shift=0.0, log_scale=0.0).forward_and_log_det(np.zeros(3))
+        distrax.MaskedCoupling(mask=mask, bijector=scale_fn, conditioner=cond).forward_and_log_det(np.zeros((4, 2), np.float32))
     with pytest.raises(ValueError):
         distrax.RationalQuadraticSpline(np.zeros(5), 0.0, 1.0)
     with pytest.raises(ValueError):
@@ -418,3 +425,88 @@ def test_two_threads_two_handles_first_launches(distrax):
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res.pop("errors") == []
     assert len(res) == 12 and all(v <= 1e-5 for v in res.values()), res
+
+
+def test_standalone_inner_bijectors(distrax):
+    """The distrax.Bijector protocol (README.md:32-57 of the reference) on the INNER bijectors themselves, outside any
+    MaskedCoupling: ScalarAffine(shift, log_scale | scale) (src/real_nvp_toy_densities.py:86) and
+    RationalQuadraticSpline(params, range_min, range_max) (src/maf_toy_densities.py:87) evaluate explicit parameter
+    arrays through nf_elementwise_apply -- against oracle.scalar_affine_* / rqs_fwd / rqs_inv, tails, range edges and
+    the hand-worked spline case included; event_ndims_in = 0, so the log-det has x's shape."""
+    import os
+    rng = np.random.default_rng(42)
+    # --- ScalarAffine, log_scale form, distrax-style broadcasting ([5,1] against [1,3])
+    x = rng.standard_normal((5, 3)).astype(np.float32) * 3
+    shift = rng.standard_normal((1, 3)).astype(np.float32)
+    ls = (rng.standard_normal((5, 1)) * 0.7).astype(np.float32)
+    b = distrax.ScalarAffine(shift=shift, log_scale=ls)
+    y, ld = b.forward_and_log_det(x)
+    yr, ldr = O.scalar_affine_fwd(x.astype(np.float64), shift.astype(np.float64), ls.astype(np.float64))
+    assert y.shape == (5, 3) and ld.shape == (5, 3)
+    assert (np.abs(y - yr) <= tol(yr)).all() and (np.abs(ld - ldr) <= tol(ldr)).all()
+    xb, ldb = b.inverse_and_log_det(y)
+    xr, ldbr = O.scalar_affine_inv(y.astype(np.float64), shift.astype(np.float64), ls.astype(np.float64))
+    assert (np.abs(xb - xr) <= tol(xr)).all() and (np.abs(ldb - ldbr) <= tol(ldbr)).all()
+    assert (np.abs(b.forward(x) - y) == 0).all() and (np.abs(b.inverse_log_det_jacobian(y) - ldb) == 0).all()
+    # the hand-worked affine layer (tests/golden/affine_hand_case.npz): shift and log_scale from its 2-2-2-2 relu MLP
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "affine_hand_case.npz"))
+    xm = g["x"].astype(np.float64) * np.array([0.0, 1.0])          # layer 0 passes dim 1 through (mask [F, T])
+    h = np.maximum(xm @ g["W1"] + g["b1"], 0)
+    h = np.maximum(h @ g["W2"] + g["b2"], 0)
+    p = (h @ g["W3"] + g["b3"]).astype(np.float32)
+    y0, l0 = distrax.ScalarAffine(shift=p[:, 0], log_scale=p[:, 1]).forward_and_log_det(g["x"][:, 0])
+    assert abs(y0[0] - g["y"][0, 0]) <= 1e-6 and abs(l0[0] - g["logdet"][0]) <= 1e-6
+    # --- scale form (negative scales included): y = scale x + shift, logdet = log|scale|
+    scale = np.array([[2.0], [-0.5], [1e-3], [-7.0], [1.0]], np.float32)
+    b = distrax.ScalarAffine(shift=shift, scale=scale)
+    y, ld = b.forward_and_log_det(x)
+    assert (np.abs(y - (scale.astype(np.float64) * x + shift)) <= tol(y)).all()
+    assert (np.abs(ld - np.broadcast_to(np.log(np.abs(scale.astype(np.float64))), (5, 3))) <= 1e-6).all()
+    xb, ldb = b.inverse_and_log_det(y)
+    assert (np.abs(xb - x) <= 1e-4 * np.maximum(1, np.abs(x))).all() and (np.abs(ldb + ld) <= 1e-6).all()
+    with pytest.raises(ValueError):
+        distrax.ScalarAffine(shift=shift, scale=scale, log_scale=ls)
+    # --- RationalQuadraticSpline: register kernels (K = 4, 12), the run-time-K kernel (K = 5), ragged sizes
+    for K, rows, D, lo, hi in ((12, 777, 2, -8.0, 8.0), (4, 33, 3, -3.0, 4.0), (5, 1000, 1, -2.0, 2.0), (8, 1, 1, 0.0, 1.0)):
+        P = 3 * K + 1
+        params = (rng.standard_normal((rows, D, P)) * 1.5).astype(np.float32)
+        x = (rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), (rows, D))).astype(np.float32)
+        x.reshape(-1)[:2] = (lo, hi) if x.size >= 2 else lo                         # exact range edges
+        b = distrax.RationalQuadraticSpline(params, range_min=lo, range_max=hi)
+        xp, yp, sl = O.rqs_knots(params, lo, hi)
+        yr, ldr = O.rqs_fwd(x, xp, yp, sl)
+        y, ld = b.forward_and_log_det(x)
+        assert y.shape == x.shape and ld.shape == x.shape
+        ok = (np.abs(y - yr) <= tol(yr)) & (np.abs(ld - ldr) <= tol(ldr))
+        assert ok.mean() >= 0.998 and (np.abs(y - yr) <= 10 * tol(yr)).all() and (np.abs(ld - ldr) <= 10 * tol(ldr)).all(), \
+            (K, ok.mean(), np.abs(y - yr).max(), np.abs(ld - ldr).max())
+        # inverse: by its forward error, or -- where dx/dy is large -- by its backward error
+        yq = yr.astype(np.float32)
+        xb, ldb = b.inverse_and_log_det(yq)
+        xr, ldbr = O.rqs_inv(yq, xp, yp, sl)
+        fwd_ok = (np.abs(xb - xr) <= tol(xr)) & (np.abs(ldb - ldbr) <= tol(ldbr))
+        yb, ldf = O.rqs_fwd(xb.astype(np.float64), xp, yp, sl)
+        bwd_ok = (np.abs(yb - yq) <= tol(yq)) & (np.abs(ldb + ldf) <= 10 * tol(ldf))
+        assert (fwd_ok | bwd_ok).all(), (K, (~(fwd_ok | bwd_ok)).sum())
+        # one parameter set broadcast over a batch of inputs (distrax broadcasts params' batch dims)
+        one = distrax.RationalQuadraticSpline(params[0], range_min=lo, range_max=hi)
+        yy, ll = one.forward_and_log_det(x)
+        yr1, ldr1 = O.rqs_fwd(x, *(a[0] for a in (xp, yp, sl)))
+        assert (np.abs(yy - yr1) <= 10 * tol(yr1)).all() and (np.abs(ll - ldr1) <= 10 * tol(ldr1)).all()
+    # the spline worked by hand in exact rational arithmetic (tests/golden/rqs_hand_case.npz): parameters from its MLP
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rqs_hand_case.npz"))
+    for sfx in ("", "_k4"):
+        K = int(g["num_bins" + sfx])
+        xm = g["x" + sfx].astype(np.float64) * np.array([0.0, 1.0])
+        h = np.maximum(xm @ g["W1" + sfx] + g["b1" + sfx], 0)
+        h = np.maximum(h @ g["W2" + sfx] + g["b2" + sfx], 0)
+        p = (h @ g["W3" + sfx] + g["b3" + sfx]).astype(np.float32)[:, :3 * K + 1]   # dim 0 is the transformed one
+        b = distrax.RationalQuadraticSpline(p, range_min=-2.0, range_max=2.0, min_bin_size=float(g["min_bin_size" + sfx]),
+                                            min_knot_slope=0.5)
+        y, ld = b.forward_and_log_det(g["x" + sfx][:, 0])
+        assert (np.abs(y - g["y" + sfx][:, 0]) <= tol(g["y" + sfx][:, 0])).all()
+        assert (np.abs(ld - g["logdet" + sfx]) <= tol(g["logdet" + sfx])).all()
+        xb, ldb = b.inverse_and_log_det(g["y" + sfx][:, 0].astype(np.float32))
+        assert (np.abs(xb - g["x" + sfx][:, 0]) <= tol(g["x" + sfx][:, 0])).all() and (np.abs(ldb + g["logdet" + sfx]) <= 1e-5).all()
+    with pytest.raises(ValueError):
+        distrax.RationalQuadraticSpline(np.zeros((3, 12), np.float32), range_min=-1.0, range_max=1.0)
