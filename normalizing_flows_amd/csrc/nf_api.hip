@@ -231,6 +231,10 @@ struct nf_flow {
     signed char *d_fshift = nullptr, *d_bshift = nullptr;
     float *d_state_v = nullptr, *d_state_g = nullptr;
     long long state_rows = 0;
+    // the fused spline flow (rqs2d_bwd): its forward walk records every layer's input, [L][tape_rows][2]
+    bool rqs_fused = false;
+    float* d_tape = nullptr;
+    long long tape_rows = 0;
     long long step = 0;
     bool ready = false, dirty = false;  // dirty: device weights are newer than h_weights
     // flows that train through the general plan: the optimiser's vectors (d_m, d_v) and its weights (plan.d_weights,
@@ -672,7 +676,7 @@ void nf_flow_destroy(nf_flow* f) {
     hipFree(t.d_canon); hipFree(t.d_grad); hipFree(t.d_m); hipFree(t.d_v); hipFree(t.d_bwd_img); hipFree(t.d_bwd_img_x3);
     hipFree(t.d_partials); hipFree(t.d_gmap[0]); hipFree(t.d_gmap[1]); hipFree(t.d_gscale[0]);
     hipFree(t.d_gscale[1]); hipFree(t.d_fsrc); hipFree(t.d_bsrc); hipFree(t.d_fshift); hipFree(t.d_bshift);
-    hipFree(t.d_state_v); hipFree(t.d_state_g);
+    hipFree(t.d_state_v); hipFree(t.d_state_g); hipFree(t.d_tape);
   }
   f->plan.release();
   hipFree(f->d_x); hipFree(f->d_y); hipFree(f->d_ld); hipFree(f->d_lp);
@@ -768,7 +772,12 @@ static int set_weights_internal(nf_flow* f, const float* packed, size_t count) {
     if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     f->train.canon_stale = false;
   }
-  if (f->train.ready && f->path == PATH_RQS2D_H64) {
+  if (f->train.ready && f->path == PATH_RQS2D_H64 && f->train.rqs_fused) {
+    NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
+    NF_TRY(launch_repack(f->train.d_canon, f->train.d_bsrc, f->train.d_bshift, f->train.d_bwd_img,
+                         (size_t)d.num_layers * rqs2d_bwd::kImageFloats, f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
+  } else if (f->train.ready && f->path == PATH_RQS2D_H64) {
     NF_HIP(hipMemcpy(f->train.d_canon, packed, count * sizeof(float), hipMemcpyHostToDevice));
     NF_TRY(f->plan.build(d, packed));
     NF_TRY(f->plan.prepare_backward());
@@ -1354,17 +1363,19 @@ namespace nf {
 // image <- canonical maps, derived from the pack functions themselves: pack a layer whose
 // "weights" are their own canonical index + 1 and read back which index (and which power of
 // two) landed in every image element.
+// (last_out: width of the last Linear -- 2 for the affine flow, 2 (3K+1) for the spline flow; ids stay exact in float32)
 template <typename PackFn>
 static void derive_repack_map(PackFn pack, int image_floats, int cond_dim, int layer, std::vector<int>& src,
-                              std::vector<signed char>& shift) {
-  std::vector<float> ids(affine2d_bwd::kCanonFloats);
-  for (int e = 0; e < affine2d_bwd::kCanonFloats; ++e) ids[e] = (float)(e + 1);
+                              std::vector<signed char>& shift, int last_out = 2) {
+  const int canon = 128 + 64 + 4096 + 64 + 64 * last_out + last_out;
+  std::vector<float> ids(canon);
+  for (int e = 0; e < canon; ++e) ids[e] = (float)(e + 1);
   const float* W1 = ids.data();
   const float* b1 = W1 + 128;
   const float* W2 = b1 + 64;
   const float* b2 = W2 + 4096;
   const float* W3 = b2 + 64;
-  const float* b3 = W3 + 128;
+  const float* b3 = W3 + 64 * last_out;
   std::vector<float> img(image_floats);
   pack(W1, b1, W2, b2, W3, b3, cond_dim, img.data());
   for (int e = 0; e < image_floats; ++e) {
@@ -1374,7 +1385,7 @@ static void derive_repack_map(PackFn pack, int image_floats, int cond_dim, int l
     if (v == 0.f) { src.push_back(-1); shift.push_back(0); continue; }
     if (v > 1e12f) { sh = 64; id = ldexpf(v, -64); }
     else if (v < 1e-12f) { sh = -64; id = ldexpf(v, 64); }
-    src.push_back(layer * affine2d_bwd::kCanonFloats + (int)(id + 0.5f) - 1);
+    src.push_back(layer * canon + (int)(id + 0.5f) - 1);
     shift.push_back((signed char)sh);
   }
 }
@@ -1388,16 +1399,21 @@ static int upload(T** dst, const std::vector<T>& host) {
 
 // flows whose gradient comes from the general plan: every masked kind without a fused backward
 static const nf_flow_desc& d_of(const nf_flow* f) { return f->desc; }
+// the fused spline flow has its own backward (nf_rqs2d_bwd.hip); NF_NO_RQS2D_BWD=1 keeps the general plan for A/B
+static bool rqs_fused_backward(const nf_flow* f) {
+  return f->path == PATH_RQS2D_H64 && !f->sw.no_rqs2d_bwd && rqs2d_bwd::supported_bins(f->desc.rqs_bins);
+}
 static bool trains_through_plan(const nf_flow* f) {
   const int k = f->desc.kind;
-  return (f->path == PATH_GENERIC || f->path == PATH_RQS2D_H64) &&
+  return (f->path == PATH_GENERIC || (f->path == PATH_RQS2D_H64 && !rqs_fused_backward(f))) &&
          (k == NF_KIND_AFFINE_MASKED || k == NF_KIND_RQS_MASKED);
 }
 
 static int ensure_train(nf_flow* f, long long rows) {
   const bool split = f->path == PATH_SPLIT2D_SMALL && split2d::bwd_supported(f->desc.hidden[0]);
   const bool planned = trains_through_plan(f);
-  if (f->path != PATH_AFFINE2D_H64 && !split && !planned) {
+  const bool rqsf = rqs_fused_backward(f);
+  if (f->path != PATH_AFFINE2D_H64 && !split && !planned && !rqsf) {
     set_error("the backward pass is built for the masked coupling kinds (affine and spline, any event size) and "
               "the split flow of src/real_nvp.py (D = 2, MLP 1-H-2, H = 4, 8, 16)");
     return NF_ERR_UNSUPPORTED;
@@ -1438,6 +1454,57 @@ static int ensure_train(nf_flow* f, long long rows) {
     t.step = 0;
     if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
     t.ready = true;
+  }
+  if (!t.ready && rqsf) {
+    // as the fused affine flow below: canonical weights, gradient and Adam state on the device; after an optimiser
+    // step the forward and the backward image are refreshed from the canonical vector by index maps derived from the
+    // pack functions themselves
+    const int K = d.rqs_bins, P2 = 2 * (3 * K + 1);
+    NF_HIP(hipMalloc(&t.d_canon, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_grad, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_m, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_v, n * sizeof(float)));
+    NF_HIP(hipMemcpy(t.d_canon, f->h_weights.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    NF_HIP(hipMemset(t.d_m, 0, n * sizeof(float)));
+    NF_HIP(hipMemset(t.d_v, 0, n * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_bwd_img, (size_t)d.num_layers * rqs2d_bwd::kImageFloats * sizeof(float)));
+    NF_HIP(hipMalloc(&t.d_partials, (size_t)rqs2d_bwd::grid_blocks() * d.num_layers * rqs2d_bwd::kPartialFloats * sizeof(float)));
+    for (int c = 0; c < 2; ++c) {
+      std::vector<int> map(rqs2d_bwd::canon_floats(K));
+      std::vector<float> scale(rqs2d_bwd::canon_floats(K));
+      rqs2d_bwd::build_gather_map(c, K, map.data(), scale.data());
+      NF_TRY(upload(&t.d_gmap[c], map));
+      NF_TRY(upload(&t.d_gscale[c], scale));
+    }
+    std::vector<int> fsrc, bsrc;
+    std::vector<signed char> fshift, bshift;
+    auto pack_f = [K](const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                      int cond, float* img) { rqs2d::pack_layer(W1, b1, W2, b2, W3, b3, cond, K, img); };
+    auto pack_b = [K](const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                      int cond, float* img) { rqs2d_bwd::pack_layer(W1, b1, W2, b2, W3, b3, cond, K, img); };
+    for (int l = 0; l < d.num_layers; ++l) {
+      const int cond = (d.first_mask_parity + l) & 1;
+      derive_repack_map(pack_f, rqs2d::kLayerFloats, cond, l, fsrc, fshift, P2);
+      derive_repack_map(pack_b, rqs2d_bwd::kImageFloats, cond, l, bsrc, bshift, P2);
+    }
+    NF_TRY(upload(&t.d_fsrc, fsrc));
+    NF_TRY(upload(&t.d_fshift, fshift));
+    NF_TRY(upload(&t.d_bsrc, bsrc));
+    NF_TRY(upload(&t.d_bshift, bshift));
+    NF_TRY(launch_repack(t.d_canon, t.d_bsrc, t.d_bshift, t.d_bwd_img,
+                         (size_t)d.num_layers * rqs2d_bwd::kImageFloats, f->stream));
+    t.rqs_fused = true;
+    t.step = 0;
+    if (f->d_adam_bias) { hipFree(f->d_adam_bias); f->d_adam_bias = nullptr; }
+    t.ready = true;
+  }
+  if (t.rqs_fused && rows > t.tape_rows) {
+    NF_HIP(hipStreamSynchronize(f->stream));
+    hipFree(t.d_tape);
+    t.d_tape = nullptr;
+    t.tape_rows = 0;
+    NF_HIP(hipMalloc(&t.d_tape, sizeof(float) * 2 * (size_t)rows * d.num_layers));
+    t.tape_rows = rows;
   }
   if (!t.ready) {
     NF_HIP(hipMalloc(&t.d_canon, n * sizeof(float)));
@@ -1516,6 +1583,7 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
       f->plan.record_tape = false;
       NF_TRY(s);
     } else {
+      if (t.rqs_fused) io.tape = t.d_tape;   // [L][rows_local][2]: the kernel indexes it with io.rows
       NF_TRY(run_chain_device(f, io, &grid, /*allow_x3=*/false));
     }
   }
@@ -1536,6 +1604,15 @@ static int enqueue_nll_grad(nf_flow* f, const float* x_dev, long long rows_local
       if (canon_grad) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
       else NF_TRY(flow_allreduce_f32(f, f->plan.bwd.d_grad, f->plan.bwd.n_weights, f->stream));
     }
+    return NF_OK;
+  }
+  if (t.rqs_fused) {
+    int nparts = 0;
+    NF_TRY(rqs2d_bwd::launch_chain(t.d_bwd_img, d, t.d_tape, t.d_state_v, t.d_state_g, t.d_partials, rows_local, f->stream,
+                                   &nparts));
+    NF_TRY(rqs2d_bwd::launch_gather(t.d_partials, nparts, d, t.d_gmap[0], t.d_gmap[1], t.d_gscale[0], t.d_gscale[1],
+                                    t.d_grad, rows_global, f->stream));
+    if (f->comm) NF_TRY(flow_allreduce_f32(f, t.d_grad, f->weight_count, f->stream));
     return NF_OK;
   }
   if (f->path == PATH_SPLIT2D_SMALL) {
@@ -1651,6 +1728,10 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
                           f->stream));
     t.bwd_x3_stale = true;
   }
+  if (t.rqs_fused)
+    NF_TRY(launch_repack2(t.d_canon, t.d_fsrc, t.d_fshift, f->d_wimg, (size_t)f->desc.num_layers * rqs2d::kLayerFloats,
+                          t.d_bsrc, t.d_bshift, t.d_bwd_img, (size_t)f->desc.num_layers * rqs2d_bwd::kImageFloats,
+                          f->stream));
   if (trains_through_plan(f)) {
     NF_TRY(f->plan.refresh_after_step(f->stream));
     t.canon_stale = true;

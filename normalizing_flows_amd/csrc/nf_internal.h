@@ -73,6 +73,8 @@ struct ChainIO {
   int inverse_op;              // 1: x = (y - shift) * exp(-ls), logdet -= ls
   int add_base;                // 1: logprob includes the base log-density
   int base;                    // nf_base
+  float* tape;                 // [num_layers][rows][D] or null: the input of every walked layer, at that layer's index
+                               // (the training forward of the fused spline flow: rqs2d_bwd reads it)
 };
 
 // ---- path 1: masked affine coupling, D = 2, conditioner 2 -> 64 -> 64 -> 2 ------
@@ -191,6 +193,51 @@ int launch(const float* wimg, const nf_flow_desc& d, const ChainIO& io, hipStrea
 int max_grid();
 bool supported_bins(int K);
 }  // namespace rqs2d
+
+// ---- backward of path 1b (training step of the 2-D spline flow) ------------------------------
+// The `update` of src/maf_toy_densities.py:168-176 for the flows the fused spline kernel runs: one launch walks the
+// whole chain backwards (layer 0 first), recomputing the conditioner per 32-sample tile from the layer's recorded INPUT
+// (the forward kernel's `tape`, 8 B per sample and layer: the float32 inverse of a spline is not accurate enough to
+// rebuild it) -- no activation, no parameter tensor and no parameter gradient ever reaches HBM.
+namespace rqs2d_bwd {
+constexpr int kMaxParams = 37;          // 3K+1, K <= 12
+// canonical weights of one layer: W1[2][64], b1[64], W2[64][64], b2[64], W3[64][2P], b3[2P]  (P = 3K+1)
+inline int canon_floats(int K) { return 128 + 64 + 4096 + 64 + 130 * (3 * K + 1); }
+// LDS image of one layer (floats): the forward kernel's operands for the recompute + the transposed ones
+constexpr int oA2 = 0;                  // [32 kstep][64 lane][2 mtile]   W2 * 2^64, natural k (recompute of a2)
+constexpr int oA2T = 4096;              // [32 kstep'][64 lane][2 mtile'] W2 rows, k in accumulator order (g1 = W2 g2)
+constexpr int oA3 = 8192;               // [8 kgroup][64 lane][4 kstep']  bin-size + boundary-slope rows (rqs2d::kA3)
+constexpr int oA3T = oA3 + 2048;        // [K kstep][64 lane][2 mtile]    W3 columns (width s | height s) by hidden unit
+constexpr int oWS = oA3T + 12 * 128;    // [2 half][32 slot][12][2]       slope column pairs (rqs2d::kWS)
+constexpr int oW1B1 = oWS + 2 * 32 * 12 * 2;  // [64 k][2]  (w1, b1) * 2^-64
+constexpr int oW1acc = oW1B1 + 128;     // [2 half][2 mtile][16 reg]      w1 in accumulator order
+constexpr int oB1acc = oW1acc + 64;
+constexpr int oB2 = oB1acc + 64;
+constexpr int oB3 = oB2 + 64;           // [2 half][16 slot]
+constexpr int oBS = oB3 + 32;           // [12][2]
+constexpr int kImageFloats = oBS + 24;  // 13,688 floats = 54,752 B
+// one workgroup's partial gradient of one layer (floats)
+constexpr int pW2 = 0;                  // [2 mk][2 mj][16 reg][64 lane]  (still carries 2^-64)
+constexpr int pB2 = 4096;               // [64 units]
+constexpr int pB1 = pB2 + 64;
+constexpr int pW1 = pB1 + 64;
+constexpr int pW3 = pW1 + 64;           // [64 units][40]: the transformed dim's 3K+1 columns, canonical order
+constexpr int pB3 = pW3 + 64 * 40;      // [40]
+constexpr int kPartialFloats = pB3 + 40;  // 6,888
+void pack_layer(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                int cond_dim, int K, float* image);
+void build_gather_map(int cond_dim, int K, int* map /*[canon_floats(K)]*/, float* scale);
+int grid_blocks();
+bool supported_bins(int K);
+struct SplineConst { float range_min, range_max, min_bin, min_slope, slope_offset; };
+// tape [num_layers][rows][2]: every layer's input (layer l's slice = what the forward walk fed layer l);
+// z [rows][2]: the chain's output; G [rows][2]: scratch (d loss_i / d state, in and out);
+// partials [num_layers][grid_blocks()][kPartialFloats]
+int launch_chain(const float* images, const nf_flow_desc& d, const float* tape, const float* z, float* G,
+                 float* partials, long long rows, hipStream_t stream, int* out_parts);
+int launch_gather(const float* partials, int nparts, const nf_flow_desc& d, const int* map0, const int* map1,
+                  const float* scale0, const float* scale1, float* grad, long long rows_global, hipStream_t stream);
+}  // namespace rqs2d_bwd
 
 // ---- path 1b, optional "bf16x3" matmul: both MFMA passes on split-bf16 operands ----------------
 namespace rqs2d_x3 {

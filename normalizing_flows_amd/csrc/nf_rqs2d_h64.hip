@@ -173,6 +173,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void chain_kernel(Params p) 
       if (more) NF_FETCH(li + 1 < nlay ? li + 1 : 0);
 
       if (live) {
+      // training forward: this layer's input, 8 B per sample (rqs2d_bwd recomputes everything else from it)
+      if (!INV && io.tape != nullptr) {
+        const int cd = (c_first + li) & 1;   // the dim this layer conditions on: xc holds it, xt the transformed one
+        float2* tp = reinterpret_cast<float2*>(io.tape) + (size_t)layer_of(li) * rows;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          if (h == 0 && idx[t] < rows) tp[idx[t]] = cd ? make_float2(xt[t], xc[t]) : make_float2(xc[t], xt[t]);
+      }
       const float* L = lds + (step & 1) * kLayerFloats;
       const float2* a2 = reinterpret_cast<const float2*>(L + kA2) + lane;
       const float4* a3 = reinterpret_cast<const float4*>(L + kA3) + lane;
