@@ -27,6 +27,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  (void)hipGetLastError();  // reported here: not again by the next launch's hipGetLastError() in some other call
   set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
   return e == hipErrorNoDevice ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
 }

@@ -613,7 +613,8 @@ int grid_blocks() { return 256; }
 template <int K>
 static int launch_k(const Params& p, int grid, hipStream_t stream) {
   const size_t lds_bytes = (size_t)kImageFloats * sizeof(float);   // + the kernel's static scratch
-  NF_DYN_LDS(64 * 1024, &chain_kernel<K>);
+  // (the attribute bounds dynamic + static: 54.8 KB of image beside 98.8 KB of scratch is what 160 KB holds)
+  NF_DYN_LDS((int)lds_bytes, &chain_kernel<K>);
   hipLaunchKernelGGL(chain_kernel<K>, dim3(grid), dim3(kWaves * 64), lds_bytes, stream, p);
   NF_HIP(hipGetLastError());
   return NF_OK;

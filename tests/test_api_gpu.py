@@ -497,7 +497,7 @@ def test_standalone_inner_bijectors(distrax):
         # one parameter set broadcast over a batch of inputs (distrax broadcasts params' batch dims)
         one = distrax.RationalQuadraticSpline(params[0], range_min=lo, range_max=hi)
         yy, ll = one.forward_and_log_det(x)
-        yr1, ldr1 = O.rqs_fwd(x, *(a[0] for a in (xp, yp, sl)))
+        yr1, ldr1 = O.rqs_fwd(x, *(np.broadcast_to(a[0], a.shape) for a in (xp, yp, sl)))
         assert ((np.abs(yy - yr1) <= tol(yr1)) & (np.abs(ll - ldr1) <= tol(ldr1))).mean() >= 0.99
         assert (np.abs(yy - yr1) <= 30 * tol(yr1)).all() and (np.abs(ll - ldr1) <= 30 * tol(ldr1)).all()
     # the spline worked by hand in exact rational arithmetic (tests/golden/rqs_hand_case.npz): parameters from its MLP
