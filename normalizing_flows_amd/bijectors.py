@@ -481,6 +481,14 @@ class Chain(Bijector):
         return cached[1], first.event_shape
 
     def _walk(self, direction: int, v):
+        from . import haiku_like
+        frame = haiku_like.current_frame()
+        if frame is not None and frame.mode in ("init", "plan"):
+            # hk.transform(...).init and apply's dry run build the model and evaluate nothing (haiku_like.py)
+            if isinstance(v, (DeviceArray, DeviceView)):
+                return v, DeviceArray((v.shape[0],))
+            a = np.asarray(v, np.float32)
+            return np.zeros_like(a), np.zeros(a.shape[:a.ndim - self.event_ndims_in], np.float32)
         # the base density plays no part in a chain walk: reuse whichever handle exists
         base = next(iter(self._flows), _lib.BASE_STD_NORMAL)
         flow, event_shape = self.lowered(base)

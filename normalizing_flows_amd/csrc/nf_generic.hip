@@ -491,6 +491,9 @@ static float* splitk_scratch(hipStream_t stream, size_t floats) {
 // relu' / leaky_relu' of `aux` (an activation OUTPUT of the same shape and leading dimension as C)
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
                        int M, int N, int K, int act, hipStream_t stream, const float* aux) {
+  // few rows (the reference's batch of 128): the whole product in one launch of sixteen-wave workgroups
+  if (gemm_small_m_applicable(A, lda, M, N, K) && !switches().gemm_simple)
+    return launch_gemm_small_m(A, lda, W, bias, Cm, ldc, M, N, K, act, stream, aux);
   const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
   if (aligned && N >= 128 && K >= 32 && !switches().gemm_simple) {

@@ -48,6 +48,7 @@ struct Switches {
   bool no_small_m = false;               // NF_NO_SMALL_M: the general path's small-batch (M <= 256) kernels off
   int affine2d_tune[2] = {0, 0}, affine2d_x3_tune[2] = {0, 0}, rqs2d_tune[2] = {0, 0}, rqs2d_x3_tune[2] = {0, 0};  // T, WAVES; 0 = unset
   int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
+  int small_m_nt = 0;                         // NF_SMALL_M_NT = 1 | 2 | 4: column blocks per workgroup of gemm_small_m_kernel
   long long inline_tail_rows = 0;             // NF_INLINE_TAIL_LG (clamped to [0, 40]); 0 = unset
   static Switches from_env();
 };
@@ -282,6 +283,10 @@ struct RqsConst {
 RqsConst make_rqs_const(const nf_flow_desc& d);
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K,
                 int act, hipStream_t stream, const float* aux = nullptr);
+// nf_gemm_small_m.hip: one Linear at M <= 256 rows in one launch (no split-K slabs, no reduction launch)
+bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K);
+int launch_gemm_small_m(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N,
+                        int K, int act, hipStream_t stream, const float* aux);
 int launch_transform(const nf_flow_desc& d, float* y, float* ld, const float* params, long long n, int par,
                      int inverse_op, const RqsConst& rc, hipStream_t stream);
 // stand-alone ScalarAffine on explicit per-element parameters (nf_elementwise_apply); y / ld may be null

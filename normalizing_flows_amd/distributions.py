@@ -240,6 +240,10 @@ class Transformed(Distribution):
     def nll(self, value) -> float:
         """-mean(log_prob(value)) with a float64, fixed-order reduction on the GPU
         (loss_fn / eval_fn, src/real_nvp_toy_densities.py:139-151)."""
+        from . import haiku_like
+        frame = haiku_like.current_frame()
+        if frame is not None and frame.mode in ("init", "plan"):
+            return 0.0
         flow, direction = self._lowered()
         if direction != _lib.DIR_CHAIN_FORWARD:
             raise NotImplementedError("nll is fused for Transformed(base, Inverse(Chain(...))) only")

@@ -107,7 +107,8 @@ class Transformed:
         # CouplingFlow): see Chain.lowered.  Two models of one architecture built by one function have different
         # module names, hence different slots.
         self.flow_cache: Dict[tuple, tuple] = {}
-        self._validated: Optional[frozenset] = None   # module names of the last params tree the dry run accepted
+        self._validated: Optional[frozenset] = None   # (module name, w.shape, b.shape) of the last params tree the dry
+                                                      # run accepted
 
     def init(self, rng, *args, **kwargs) -> Dict[str, Dict[str, np.ndarray]]:
         seed = rng if isinstance(rng, (int, np.integer)) else int(np.asarray(rng).reshape(-1)[-1])
@@ -126,11 +127,17 @@ class Transformed:
             args = args[1:]
         if not isinstance(params, Mapping):
             raise ValueError("params must be the dict init() returned (haiku module name -> {'w', 'b'})")
-        names = frozenset(params)
+        # (names AND shapes: a tree with the same module names but a wrong shape in a later module must not skip the
+        # dry run and fail after earlier models have already run on the GPU)
+        names = frozenset((name, tuple(np.shape(mod.get("w"))), tuple(np.shape(mod.get("b")))) if isinstance(mod, Mapping)
+                          else (name, None, None) for name, mod in params.items())
         if names != self._validated:
             # dry run: the function builds its models against `params` (missing module, wrong shape and a wrong
             # number of coupling layers raise here), evaluates nothing -- so a bad tree fails before anything
-            # reaches the GPU even when the function builds several models
+            # reaches the GPU even when the function builds several models.  (Every evaluation entry point of the
+            # surface is a stub in this mode: Transformed.log_prob / sample / sample_and_log_prob / nll and the
+            # bijectors' forward / inverse walks return zeros of the right shape.  The function itself runs twice on
+            # such a call -- side effects of user code in it, e.g. drawing from a host rng, happen twice.)
             self._run(_Frame("plan", params, None, self), args, kwargs)
             self._validated = names
         return self._run(_Frame("apply", params, None, self), args, kwargs)

@@ -11,7 +11,7 @@ spec = O.make_rqs_spec(8, event_size=784, hidden=(512, 512, 512), num_bins=8, ra
 cfg = nfa.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=784, num_layers=8, hidden=(512, 512, 512), rqs_bins=8,
                      rqs_range_min=0.0, rqs_range_max=1.0, base=_lib.BASE_UNIFORM01)
 f = nfa.CouplingFlow(cfg, spec.layers)
-for rows in (128, 512, 2048, 8192):
+for rows in [int(v) for v in os.environ.get("NF_MNIST_ROWS", "128,512,2048,8192").split(",")]:
     x = nfa.DeviceArray.from_numpy(O.make_inputs("mnist_like", rows))
     out = nfa.DeviceArray((rows,))
     for _ in range(3):
