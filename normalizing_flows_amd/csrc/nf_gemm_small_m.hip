@@ -25,7 +25,8 @@ namespace generic {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSmallMWaves = 16;
-constexpr int kSmallMChunk = 2;   // octets (8 k each) per software-pipeline stage
+constexpr int kSmallMChunk = 4;   // octets (8 k each) per software-pipeline stage: K = 512 over sixteen waves is ONE stage
+                                  // (all of a wave's loads in flight at once; with 2 the launch took 11.4 us)
 
 template <int NT>
 __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m_kernel(const float* __restrict__ A, int lda,

@@ -685,10 +685,19 @@ __global__ __launch_bounds__(256) void rqs_masked_kernel(float* __restrict__ y, 
 // parameters through LDS with coalesced 16-byte loads (a lane's 3K+1 values are then a stride-(3K+1)
 // LDS read: odd stride, conflict-free), evaluates one (row, transformed dim) pair per thread and
 // iteration with everything in registers, and reduces each row's log-dets in a fixed order.
+// slabs.S > 0: `params` has not been formed -- it is the sum of S split-K slabs [S][rows][Dt * P] of the last Linear
+// (gemm_splitk_kernel) plus its bias: added here, in slab order, while the rows are staged (small batches: the
+// reduction launch, the parameter tensor's round trip through HBM and one dependent launch per layer disappear).
+struct SlabSum {
+  const float* slabs = nullptr;
+  const float* bias = nullptr;
+  int S = 0;
+  size_t stride = 0;   // floats between slabs
+};
 template <int K, int INV>
 __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, float* __restrict__ ld,
                                                       const float* __restrict__ params, long long rows, int D,
-                                                      int pass_parity, int R, RqsConst c) {
+                                                      int pass_parity, int R, RqsConst c, SlabSum slabs) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int P = 3 * K + 1;
   const int Dt = pass_parity == 0 ? D / 2 : (D + 1) / 2;
@@ -702,7 +711,39 @@ __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, fl
     const int nrow = (int)((rows - row0) < R ? (rows - row0) : R);
     const int nfl = nrow * Dt * P;
     const float* src = params + (size_t)row0 * Dt * P;
-    if (((size_t)row0 * Dt * P & 3) == 0) {
+    if (slabs.S > 0) {
+      // N % 4 == 0 (the caller's test): 16-byte loads, two per thread and pass with up to four slabs each in flight
+      // (one dependent 4-byte load at a time made this loop 50 us for a 9800-wide row: 38 memory latencies in a row)
+      const int N = Dt * P;
+      const float4* s0 = reinterpret_cast<const float4*>(slabs.slabs + (size_t)row0 * N);
+      const float4* b4 = reinterpret_cast<const float4*>(slabs.bias);
+      const size_t st4 = slabs.stride >> 2;
+      const int n4 = nfl >> 2, N4 = N >> 2;
+      for (int q0 = tid; q0 < n4; q0 += 512) {
+        const int q1 = q0 + 256;
+        const bool two = q1 < n4;
+        const float4 c0 = b4[q0 % N4], c1 = two ? b4[q1 % N4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        for (int sb = 0; sb < slabs.S; sb += 4) {
+          float4 t0[4], t1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool on = sb + u < slabs.S;
+            const size_t off = (size_t)(on ? sb + u : sb) * st4;
+            t0[u] = s0[off + q0];
+            t1[u] = s0[off + (two ? q1 : q0)];
+            if (!on) t0[u] = t1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {   // slab order: the reduction kernel's order of additions
+            v0.x += t0[u].x; v0.y += t0[u].y; v0.z += t0[u].z; v0.w += t0[u].w;
+            v1.x += t1[u].x; v1.y += t1[u].y; v1.z += t1[u].z; v1.w += t1[u].w;
+          }
+        }
+        reinterpret_cast<float4*>(sm)[q0] = make_float4(v0.x + c0.x, v0.y + c0.y, v0.z + c0.z, v0.w + c0.w);
+        if (two) reinterpret_cast<float4*>(sm)[q1] = make_float4(v1.x + c1.x, v1.y + c1.y, v1.z + c1.z, v1.w + c1.w);
+      }
+    } else if (((size_t)row0 * Dt * P & 3) == 0) {
       for (int q = tid * 4; q < nfl; q += 1024) {
         if (q + 3 < nfl) *reinterpret_cast<float4*>(sm + q) = *reinterpret_cast<const float4*>(src + q);
         else for (int e = q; e < nfl; ++e) sm[e] = src[e];
@@ -736,7 +777,7 @@ __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, fl
 
 template <int K>
 static bool launch_rqs_rows(float* y, float* ld, const float* params, long long rows, int D, int par, int inverse,
-                            const RqsConst& rc, hipStream_t stream) {
+                            const RqsConst& rc, hipStream_t stream, const SlabSum& slabs = SlabSum()) {
   const int P = 3 * K + 1;
   const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
   const size_t row_bytes = (size_t)Dt * P * sizeof(float);
@@ -748,10 +789,10 @@ static bool launch_rqs_rows(float* y, float* ld, const float* params, long long 
   const int grid = (int)std::min<long long>(nblk, 65536);
   if (inverse) {
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 1>), 64 * 1024) != NF_OK) return false;
-    hipLaunchKernelGGL((rqs_rows_kernel<K, 1>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
+    hipLaunchKernelGGL((rqs_rows_kernel<K, 1>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc, slabs);
   } else {
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(&rqs_rows_kernel<K, 0>), 64 * 1024) != NF_OK) return false;
-    hipLaunchKernelGGL((rqs_rows_kernel<K, 0>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc);
+    hipLaunchKernelGGL((rqs_rows_kernel<K, 0>), dim3(grid), dim3(256), lds, stream, y, ld, params, rows, D, par, R, rc, slabs);
   }
   return true;
 }
@@ -1308,6 +1349,53 @@ int launch_transform(const nf_flow_desc& d, float* yc, float* ldc, const float* 
   return NF_OK;
 }
 
+// The last Linear of a spline layer at a small batch: split-K slabs (the test is launch_gemm's), added up inside the
+// spline kernel instead of by a reduction launch.  *done = false: not this shape -- the caller takes the plain route.
+static int launch_gemm_splitk_rqs(const nf_flow_desc& d, const float* A, int lda, const float* W, const float* bias,
+                                  int M, int N, int K, float* yc, float* ldc, int par, int inverse_op, const RqsConst& rc,
+                                  hipStream_t stream, bool* done) {
+  *done = false;
+  const int D = d.event_dim;
+  const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+  const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+  if (!aligned || N < 128 || K < 32 || switches().gemm_simple || switches().no_splitk || switches().rqs_simple ||
+      gemm_small_m_applicable(A, lda, M, N, K) || N != Dt * (3 * rc.K + 1))
+    return NF_OK;
+  const int gx = (N + FBN - 1) / FBN, gy = (M + FBM - 1) / FBM;
+  const int tiles = gx * gy, ktiles = (K + FBK - 1) / FBK;
+  if (tiles > 128 || ktiles < 8) return NF_OK;
+  if (rc.K != 4 && rc.K != 6 && rc.K != 8 && rc.K != 10 && rc.K != 12 && rc.K != 16) return NF_OK;
+  if ((size_t)N * sizeof(float) > 60 * 1024) return NF_OK;   // a row's parameters must fit the spline kernel's LDS
+  NF_DYN_LDS(80 * 1024, &gemm_splitk_kernel);
+  int S = std::min((512 + tiles - 1) / tiles, ktiles / 4);
+  const int Kc = ((ktiles + S - 1) / S) * FBK;
+  S = (K + Kc - 1) / Kc;
+  float* partial = splitk_scratch(stream, (size_t)S * M * N);
+  if (partial == nullptr) { set_error("out of device memory for the split-K slabs"); return NF_ERR_HIP; }
+  hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * S), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda, W,
+                     partial, M, N, K, Kc, gx, gy);
+  NF_HIP(hipGetLastError());
+  SlabSum ss;
+  ss.slabs = partial;
+  ss.bias = bias;
+  ss.S = S;
+  ss.stride = (size_t)M * N;
+  bool ok = false;
+  switch (rc.K) {
+    case 4: ok = launch_rqs_rows<4>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+    case 6: ok = launch_rqs_rows<6>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+    case 8: ok = launch_rqs_rows<8>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+    case 10: ok = launch_rqs_rows<10>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+    case 12: ok = launch_rqs_rows<12>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+    case 16: ok = launch_rqs_rows<16>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
+  }
+  if (!ok) { set_error("spline kernel refused a shape it was checked for"); return NF_ERR_UNSUPPORTED; }
+  NF_HIP(hipGetLastError());
+  *done = true;
+  return NF_OK;
+}
+
 // y (in place) and ld (in place) already hold the chain's input state.
 int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
   const nf_flow_desc& d = desc;
@@ -1378,6 +1466,13 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
           NF_TRY(st);
           fused_transform = true;
           break;
+        }
+        if (j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3)) {
+          // small batch, float32: the slabs of the split-K product go straight into the spline kernel
+          bool done = false;
+          NF_TRY(launch_gemm_splitk_rqs(d, a, lda, d_weights + L.w_off, d_weights + L.b_off, (int)n, L.N, L.K, yc, ldc, par,
+                                        io.inverse_op, rc, stream, &done));
+          if (done) { fused_transform = true; break; }
         }
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
         if (record_tape)  // training: every Linear's output stays (hidden activations and theta)
