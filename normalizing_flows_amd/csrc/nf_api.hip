@@ -941,7 +941,23 @@ static int ensure_pipe_events(nf_flow* f) {
 // chunk c+1 arrives and chunk c-1 leaves on the side stream (pageable copies block the HOST, so they are issued in the
 // order that keeps a kernel enqueued behind them).  A row's bits do not depend on the batch it is evaluated in, so the
 // result is the unchunked call's.  0.835 -> see DESIGN 5 (profiles/host_path.py).
+// On ANY failure inside a pipelined section both streams are drained before the error is returned: copies into the
+// caller's pageable buffer may still be in flight, and the caller may free that buffer as soon as the call has failed
+// (ADVICE r03).
+struct DrainOnError {
+  nf_flow* f;
+  bool armed = true;
+  explicit DrainOnError(nf_flow* flow) : f(flow) {}
+  ~DrainOnError() {
+    if (!armed) return;
+    (void)hipStreamSynchronize(f->side);
+    (void)hipStreamSynchronize(f->stream);
+    (void)hipGetLastError();
+  }
+};
+
 static int log_prob_host_pipelined(nf_flow* f, int direction, const float* x, long long rows, float* out) {
+  DrainOnError drain(f);
   NF_TRY(ensure_stage(f, rows));
   NF_TRY(ensure_pipe_events(f));
   const long long C = kPipeChunkRows;
@@ -972,6 +988,7 @@ static int log_prob_host_pipelined(nf_flow* f, int direction, const float* x, lo
   }
   NF_HIP(hipStreamSynchronize(f->side));
   NF_HIP(hipStreamSynchronize(f->stream));
+  drain.armed = false;
   return NF_OK;
 }
 
@@ -1306,6 +1323,7 @@ int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
     // Transformed.sample(10^6) with a host array out (the scripts' last step): the base draw for all rows in one
     // launch (the unchunked call's values), the generative walk chunk by chunk, a finished chunk leaving on the side
     // stream while the next one is walked
+    DrainOnError drain(f);
     NF_TRY(ensure_pipe_events(f));
     const long long C = kPipeChunkRows, n = (rows + C - 1) / C;
     auto walk = [&](long long c) -> int {
@@ -1326,6 +1344,7 @@ int nf_sample(nf_flow* f, uint64_t seed, int64_t rows, float* out_x, int mem) {
     }
     NF_HIP(hipStreamSynchronize(f->side));
     NF_HIP(hipStreamSynchronize(f->stream));
+    drain.armed = false;
     return NF_OK;
   }
   io.x = dst;

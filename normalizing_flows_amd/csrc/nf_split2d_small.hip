@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace nf {
 namespace split2d {
 
@@ -60,26 +62,42 @@ constexpr float kLn2 = 0.69314718055994531f;
 // with A, B, C formed once per workgroup when the layer is staged (float64 sums, one rounding each): per hidden unit
 // THREE v_fma with VGPR operands (the |a| is a free source modifier) instead of fma, mul, max, fma, fma -- 14 + 3
 // vector instructions per sample and layer instead of 23, and none of the 4.2-cycle v_max (operand-form table above).
-// Not the reference's order of roundings; the same function to float32 rounding of its largest term (both signs of
-// a_k cost one rounding of |w_sk a_k| here, where the branchy form rounds w_sk act(a_k): tests hold it to the 1e-5
-// of every other kernel against float64).
-template <int INV, int HT, int S>
+// Not the reference's order of roundings: an INACTIVE unit's contribution (0 for relu, 0.01 w a for leaky_relu) is the
+// difference of two terms of size |w_sk a_k| / 2 here, so the error of an output is ~eps/2 * sum_k |w_sk| |a_k| where
+// the reference's order has eps * |result|.  For weights like the scripts' initialisation (|w| ~ 0.1, b0 = 0) that is
+// far below float32's rounding of the result itself (emulated in NumPy float32, tests/tools/split2d_abs_form_study.py:
+// 8.5e-7 scaled log_prob error for both orders); for a trained flow with strongly negative pre-activations and large
+// second-layer weights (b0 ~ -30, |w1| ~ 10, H = 16, 8 layers) the same emulation gives 1.3e-4 against 2.4e-6 (ADVICE
+// r03).  So the form is chosen per launch from the weights themselves: FORM = 0, the folded form, while
+// sum_k |w_sk| (|b0_k| + 8 |w0_k|) <= kFoldedFormBound for every staged layer and output (a worst-case error of
+// 2.4e-7 per layer), FORM = 1, the reference's order (five instructions per unit instead of three), otherwise.
+constexpr float kFoldedFormBound = 8.f;
+template <int INV, int HT, int S, int FORM, int LEAKY>
 __device__ __forceinline__ void layer(const float* __restrict__ w, int Hrt, const float (&c)[S], float (&t)[S],
                                       float (&ld2)[S]) {
   const int H = HT > 0 ? HT : Hrt;
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
-  const float4 lin = w4[H];  // {B_shift, B_logscale, A_shift, A_logscale}
+  const float4 lin = w4[H];  // FORM 0: {B_shift, B_logscale, A_shift, A_logscale}; FORM 1: {b_shift, b_logscale, ., .}
   float sh[S], ls[S];
 #pragma unroll
-  for (int u = 0; u < S; ++u) { sh[u] = fmaf(lin.z, c[u], lin.x); ls[u] = fmaf(lin.w, c[u], lin.y); }
+  for (int u = 0; u < S; ++u) {
+    sh[u] = FORM ? lin.x : fmaf(lin.z, c[u], lin.x);
+    ls[u] = FORM ? lin.y : fmaf(lin.w, c[u], lin.y);
+  }
 #pragma unroll 4
   for (int k = 0; k < H; ++k) {
-    const float4 wk = w4[k];  // {w0, b0, C_shift, C_logscale}
+    const float4 wk = w4[k];  // {w0, b0, C_shift, C_logscale} (FORM 1: w_shift, w_logscale in the last two)
 #pragma unroll
     for (int u = 0; u < S; ++u) {
       const float a = fmaf(c[u], wk.x, wk.y);
-      sh[u] = fmaf(fabsf(a), wk.z, sh[u]);
-      ls[u] = fmaf(fabsf(a), wk.w, ls[u]);
+      if (FORM) {   // src/real_nvp.py:161-171: act = leaky_relu(x @ W + b), then act @ W_last
+        const float act = LEAKY ? fmaxf(a, 0.01f * a) : fmaxf(a, 0.f);
+        sh[u] = fmaf(act, wk.z, sh[u]);
+        ls[u] = fmaf(act, wk.w, ls[u]);
+      } else {
+        sh[u] = fmaf(fabsf(a), wk.z, sh[u]);
+        ls[u] = fmaf(fabsf(a), wk.w, ls[u]);
+      }
     }
   }
 #pragma unroll
@@ -120,8 +138,9 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
   const int SL = lds_layer_floats(H);
 
   // stage the walked layers (global image per layer: w0[H], b0[H], w1[H][2], b1[2]) in the A / B / C form of layer()
-  {
-    const double alpha = LEAKY ? 0.505 : 0.5, beta = LEAKY ? 0.495 : 0.5;
+  // (form 1: the weights as they are)
+  auto stage = [&](int form) {
+    const double alpha = form ? 1.0 : (LEAKY ? 0.505 : 0.5), beta = form ? 1.0 : (LEAKY ? 0.495 : 0.5);
     for (int idx = threadIdx.x; idx < nlay * SL; idx += 256) {
       const int li = idx / SL, r = idx - li * SL;
       const float* __restrict__ src = wimg + (size_t)(io.layer_begin + li) * layer_floats(H);
@@ -129,6 +148,8 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
       double v;
       if (k < H) {
         v = e == 0 ? (double)src[k] : e == 1 ? (double)src[H + k] : beta * (double)src[2 * H + 2 * k + (e - 2)];
+      } else if (form) {
+        v = e < 2 ? (double)src[4 * H + e] : 0.0;
       } else {
         const int o = e & 1;  // output: 0 shift, 1 log-scale
         double acc = 0.0;
@@ -138,7 +159,20 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
       if ((k < H && e == 3) || (k == H && (e & 1))) v *= (double)kLog2e;
       lds[idx] = (float)v;
     }
+  };
+  // which form: every workgroup decides alike, from the weights (see layer())
+  __shared__ int use_ref_form;
+  if (threadIdx.x == 0) use_ref_form = 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < nlay * 2; q += 256) {
+    const float* __restrict__ src = wimg + (size_t)(io.layer_begin + (q >> 1)) * layer_floats(H);
+    float bound = 0.f;
+    for (int k = 0; k < H; ++k) bound += fabsf(src[2 * H + 2 * k + (q & 1)]) * (fabsf(src[H + k]) + 8.f * fabsf(src[k]));
+    if (!(bound <= kFoldedFormBound)) use_ref_form = 1;   // (NaN weights: the reference's order too)
   }
+  __syncthreads();
+  const bool ref_form = use_ref_form != 0;
+  stage(ref_form ? 1 : 0);
   __syncthreads();
 
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(io.x);
@@ -162,6 +196,8 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
 
   double sum = 0.0;
   const long long gstride = (long long)gridDim.x * 256;
+  auto walk = [&](auto form_tag) {
+  constexpr int FORM = decltype(form_tag)::value;
   long long gn = (long long)blockIdx.x * 256 + threadIdx.x;
   float4 vn[V];
 #pragma unroll
@@ -186,16 +222,16 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
     const float* L = lds + (l - io.layer_begin) * SL;
     const int Lstep = step * SL;
     if (((l & 1) ^ p.first_flip) != 0) {  // flipped layer: dim 1 conditions, dim 0 is transformed
-      layer<INV, HT, S>(L, H, d1, d0, ld2);
+      layer<INV, HT, S, FORM, LEAKY>(L, H, d1, d0, ld2);
       L += Lstep;
       ++li;
     }
     for (; li + 1 < nlay; li += 2) {
-      layer<INV, HT, S>(L, H, d0, d1, ld2);
-      layer<INV, HT, S>(L + Lstep, H, d1, d0, ld2);
+      layer<INV, HT, S, FORM, LEAKY>(L, H, d0, d1, ld2);
+      layer<INV, HT, S, FORM, LEAKY>(L + Lstep, H, d1, d0, ld2);
       L += 2 * Lstep;
     }
-    if (li < nlay) layer<INV, HT, S>(L, H, d0, d1, ld2);
+    if (li < nlay) layer<INV, HT, S, FORM, LEAKY>(L, H, d0, d1, ld2);
 
     const long long r0 = S * g;
     const bool full = r0 + S <= rows;
@@ -226,6 +262,9 @@ __global__ __launch_bounds__(256) void chain_kernel(Params p, const float* __res
         }
     }
   }
+  };  // walk
+  if (ref_form) walk(std::integral_constant<int, 1>());
+  else walk(std::integral_constant<int, 0>());
   if (io.block_sums) {
     __shared__ double red[4];
 #pragma unroll

@@ -448,6 +448,39 @@ def test_split_log_prob(nfa, density):
     assert_close(f.log_prob(x), O.a_log_prob_chain(params, flips, x), f"A log_prob {density}")
 
 
+@pytest.mark.parametrize("w0,b0,w1", [(1.0, 30.0, 10.0), (0.5, 12.0, 4.0), (0.1, 0.0, 0.1)])
+def test_split_large_weights_take_the_reference_order(nfa, w0, b0, w1):
+    """The forward kernel of the src/real_nvp.py flow folds leaky_relu into alpha a + beta |a| (three fma per hidden
+    unit) -- exact enough only while sum_k |w_sk| |a_k| is small: for an INACTIVE unit two terms of size |w a| / 2 cancel
+    (ADVICE r03).  Weights of a trained flow with strongly negative pre-activations and large second-layer weights
+    (H = 16, 8 layers; NumPy float32 emulation of the folded form: 1.3e-4 scaled, tests/tools/split2d_abs_form_study.py)
+    must therefore take the reference's order of operations, which the kernel selects per launch from the weights: the
+    same 1e-5 against float64 as every other case.  (0.1, 0, 0.1): the scripts' initialisation scale, folded form.)"""
+    rng = np.random.default_rng(1)
+    H, L = 16, 8
+    params, flips = [], []
+    for l in range(L):
+        W0 = (rng.standard_normal((1, H)) * w0).astype(np.float32)
+        B0 = (-np.abs(rng.standard_normal(H)) * b0 - b0).astype(np.float32)     # strongly negative pre-activations
+        W1 = (rng.standard_normal((H, 2)) * w1).astype(np.float32)
+        W1[:, 1] *= 0.05                                                          # keep exp(log_scale) finite
+        B1 = (rng.standard_normal(2) * 0.1).astype(np.float32)
+        params.append([[W0, B0], [W1, B1]])
+        flips.append(bool(l & 1))
+    f = split_flow(nfa, params)
+    assert f.kernel_name == "split2d_small"
+    x = O.make_inputs("energy2", 4096)
+    ref = O.a_log_prob_chain(params, flips, x)
+    assert np.isfinite(ref).all()
+    got = f.log_prob(x)
+    assert_close(got, ref, f"A log_prob, weights ({w0}, {b0}, {w1})")
+    # the generative walk and back (both directions of the same kernel)
+    from normalizing_flows_amd import _lib
+    z, ld = f.chain_apply(_lib.DIR_LAST_TO_FIRST_INVERSE, x)
+    xb, ldb = f.chain_apply(_lib.DIR_FIRST_TO_LAST_FORWARD, z)
+    assert np.abs(xb - x).max() <= 1e-3 * max(1.0, np.abs(x).max()) and np.abs(ld + ldb).max() <= 1e-4 * max(1.0, np.abs(ld).max())
+
+
 # (61, 64, .): more layers than one launch keeps in LDS (59 at width 64): two launches, the second starts on a flipped layer
 @pytest.mark.parametrize("L,H,rows", [(1, 4, 1), (2, 4, 2), (3, 7, 255), (8, 16, 513), (11, 4, 10000), (61, 64, 301)])
 def test_split_shapes(nfa, L, H, rows):
