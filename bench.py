@@ -56,7 +56,7 @@ def profiled_traffic(kernel_prefix, summary_name):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this command
     (profiles/collect_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs, reads doubled as
     MI355X_MICROARCH.md prescribes and profiles/calibrate_fetch.py confirms).  None if absent."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, summary_name)
         try:
             summary = json.load(open(path))
@@ -591,7 +591,7 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     x128 = flow.DeviceArray.from_numpy(xd.to_numpy()[:128])
     for name, cfg, layers, flop, opt in (("affine (headline flow), Adam", aff_cfg, aff_layers, 8 * FLOP_AFFINE_PER_LAYER,
                                           training.adam(1e-4)),
-                                         ("spline K=12 (general backward), Adam", rqs_cfg, rqs_layers,
+                                         ("spline K=12 (fused backward, rqs2d_bwd), Adam", rqs_cfg, rqs_layers,
                                           8 * FLOP_RQS12_PER_LAYER, training.adam(1e-4))):
         for n, x in ((rows, xd), (128, x128)):
             f = flow.CouplingFlow(cfg, layers)
@@ -621,16 +621,31 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     f.close()
     xa.free()
 
-    # f2, image shape: the reference's own MNIST training configuration (src/maf_mnist.py:34-89,159-168: 8 layers, 784-D,
-    # MLP 512 x 3, K = 8, batch 128) -- weight-bound: every step reads the 46 M live weights twice, writes their gradient
-    # and runs Adam over them (10 floats of traffic per live weight)
+    # b/d rows at the reference's own batch: log_prob of the 8-layer MNIST-shaped flow on 128 resident rows
+    # (src/maf_mnist.py:141-146 evaluates at batch 128).  Weight-bound: 184 MB of live weights per call
     mn_layers = [make_conditioner((784,), [512, 512, 512], 25, per_dim=True, rng=np.random.default_rng(534 + l),
                                   final_std=0.01).linears for l in range(8)]
     mn_cfg = flow.FlowConfig(kind=_lib.KIND_RQS_MASKED, event_dim=784, num_layers=8, hidden=(512, 512, 512), rqs_bins=8,
                              rqs_range_min=0.0, rqs_range_max=1.0, base=_lib.BASE_UNIFORM01)
     f = flow.CouplingFlow(mn_cfg, mn_layers)
-    del mn_layers
     xm = flow.DeviceArray.from_numpy((np.random.default_rng(1).integers(0, 256, (128, 784)) / 256.0).astype(np.float32))
+    lpm = flow.DeviceArray((128,))
+    step = lambda i: f.log_prob(xm, lpm)  # noqa: E731
+    wall, ev_ms, walls = measure(f, step, steps, warm, 0.2)
+    live = 8 * (392 * 512 + 512 + 2 * (512 * 512 + 512) + 512 * 9800 + 9800)
+    line("d1-d2", "log_prob, MNIST shape of src/maf_mnist.py: 8 layers, 784-D, batch 128 (the reference's evaluation batch)",
+         f.kernel_name, 128, wall, ev_ms, walls, "evals/s",
+         hbm(1, live * 4, ev_ms, "per call: the live weights streamed once; 4 dependent launches per layer (three one-launch "
+             "Linears of gemm_small_m_kernel, the split-K last Linear whose slabs the spline kernel adds), ~4.5 us of each "
+             "being the launch boundary"))
+    f.close()
+    lpm.free()
+
+    # f2, image shape: the reference's own MNIST training configuration (src/maf_mnist.py:34-89,159-168: 8 layers, 784-D,
+    # MLP 512 x 3, K = 8, batch 128) -- weight-bound: every step reads the 46 M live weights twice, writes their gradient
+    # and runs Adam over them (10 floats of traffic per live weight)
+    f = flow.CouplingFlow(mn_cfg, mn_layers)
+    del mn_layers
     opt = training.adam(1e-4)
     step = lambda i: f.train_step(xm, opt, want_nll=False)  # noqa: E731
     wall, ev_ms, walls = measure(f, step, steps, warm, 0.2)
@@ -638,7 +653,7 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     line("f2", "training step (forward + backward + Adam), MNIST shape of src/maf_mnist.py: 8 layers, 784-D, batch 128",
          f.kernel_name, 128, wall, ev_ms, walls, "samples/s",
          hbm(1, live * 4 * 10, ev_ms, "per step: the live weights read by the forward and the backward walk, their gradient "
-             "written, Adam's 7 floats per weight; launch-bound (65 split-K GEMMs with their reductions)"))
+             "written, Adam's 7 floats per weight; launch-bound (about 150 dependent launches per step)"))
     f.close()
     xm.free()
 
