@@ -39,9 +39,14 @@ def check_grads(f, spec, x, tol=2e-4):
 
 
 @pytest.mark.parametrize("K,L,parity,rows,density", [(12, 8, 1, 4096, "banana"), (12, 2, 0, 1000, "gaussian_blobs"),
-                                                     (8, 3, 1, 33, "energy2"), (4, 5, 0, 2000, "banana")])
+                                                     (8, 3, 1, 33, "energy2"), (4, 5, 0, 2000, "banana"),
+                                                     # every bin count rqs2d_bwd::chain_kernel is instantiated for;
+                                                     # 70001 rows: 2188 tiles, more than one per wave, a ragged last one
+                                                     (10, 3, 1, 500, "banana"), (6, 4, 0, 777, "energy2"),
+                                                     (12, 2, 1, 70001, "gaussian_blobs")])
 def test_spline_2d_gradient(nfa, K, L, parity, rows, density):
-    """BASELINE.json configs[2]'s flow (the fused spline kernel's handles train through the plan).
+    """BASELINE.json configs[2]'s flow: since round 4 the fused, activation-free backward (nf_rqs2d_bwd.hip; the
+    forward kernel records each layer's input, one backward launch recomputes everything else).
     banana leaves [-8, 8]: the linear tails' gradients take part."""
     spec = O.make_rqs_spec(L, num_bins=K, final_std=0.05, first_parity=parity)
     f = rqs_flow(nfa, spec, parity)
@@ -423,6 +428,31 @@ def test_skip_nonfinite_updates(nfa, kind):
     fresh.train_step(b2, opt)
     wr, wf = _flat(r.get_weights()), _flat(fresh.get_weights())
     assert np.abs(wr - wf).max() <= 1e-7 * max(1.0, np.abs(wf).max()), np.abs(wr - wf).max()
+
+
+def test_spline_2d_gradient_fused_against_plan_and_uniform_base(nfa, monkeypatch):
+    """The fused backward of the 2-D spline flow (i) against the general plan's gradient of the SAME handle shape
+    (NF_NO_RQS2D_BWD=1: the round-3 route, dual-number spline Jacobian, stored activations) -- two independent
+    derivations of the same numbers -- and (ii) with the Uniform(0,1) base of src/maf_mnist.py on [0, 1]^2: the base
+    contributes no gradient inside the cube (G starts at zero), the log-dets all of it."""
+    spec = O.make_rqs_spec(4, num_bins=8, range_min=-6.0, range_max=6.0, final_std=0.08)
+    x = O.make_inputs("energy2", 3000, seed=5)
+    f = rqs_flow(nfa, spec)
+    fused, ref = check_grads(f, spec, x)
+    monkeypatch.setenv("NF_NO_RQS2D_BWD", "1")
+    g = rqs_flow(nfa, spec)
+    monkeypatch.delenv("NF_NO_RQS2D_BWD")
+    plan, _ = check_grads(g, spec, x)
+    for l in range(4):
+        for j in range(3):
+            for which in (0, 1):
+                scale = max(np.abs(ref[l][j][which]).max(), 1e-6)
+                assert np.abs(fused[l][j][which] - plan[l][j][which]).max() <= 4e-4 * scale
+    spec_u = O.make_rqs_spec(3, num_bins=8, range_min=0.0, range_max=1.0, base="uniform01", final_std=0.3)
+    xu = np.random.default_rng(8).uniform(0.02, 0.98, (2000, 2)).astype(np.float32)
+    fu = rqs_flow(nfa, spec_u)
+    assert fu.kernel_name == "rqs2d_h64_mfma"
+    check_grads(fu, spec_u, xu)
 
 
 @pytest.mark.parametrize("K", [21, 32])
