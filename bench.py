@@ -259,8 +259,10 @@ def main():
     comm = None
     rccl_error = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("NF_BENCH_FORCE_DIST") == "1":
+        import datetime
         import torch.distributed as dist  # gloo: CPU-side rendezvous only
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (a rank that died before the rendezvous must not leave the others waiting for gloo's default 30 minutes)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         from normalizing_flows_amd import sharding
         try:
             # every step that can fail on one rank alone (device, librccl, the id, the init itself) is agreed on

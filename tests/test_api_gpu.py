@@ -517,3 +517,52 @@ def test_standalone_inner_bijectors(distrax):
         assert (np.abs(xb - g["x" + sfx][:, 0]) <= tol(g["x" + sfx][:, 0])).all() and (np.abs(ldb + g["logdet" + sfx]) <= 1e-5).all()
     with pytest.raises(ValueError):
         distrax.RationalQuadraticSpline(np.zeros((3, 12), np.float32), range_min=-1.0, range_max=1.0)
+
+
+def test_elementwise_apply_abi(distrax):
+    """nf_elementwise_apply through raw ctypes: device pointers (no staging), either output NULL, n = 0, and the
+    argument errors (the reference raises ValueError: NF_ERR_INVALID here) -- unknown kind, 3K+1 mismatch caught by the
+    bin / range checks of distrax.RationalQuadraticSpline's constructor, NULL inputs."""
+    import ctypes as C
+    from normalizing_flows_amd import _lib
+    from normalizing_flows_amd.flow import DeviceArray
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, K = 1000, 6
+    x = rng.uniform(-4, 4, n).astype(np.float32)
+    params = (rng.standard_normal((n, 3 * K + 1)) * 0.8).astype(np.float32)
+    desc = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION, kind=_lib.ELEM_RQS, rqs_bins=K, rqs_range_min=-3.0,
+                                rqs_range_max=3.0, rqs_min_bin_size=1e-4, rqs_min_knot_slope=1e-4)
+    xd, pd = DeviceArray.from_numpy(x), DeviceArray.from_numpy(params)
+    yd, ld = DeviceArray((n,)), DeviceArray((n,))
+    _lib.check(lib.nf_elementwise_apply(C.byref(desc), 0, xd.ptr, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE))
+    yr, lr = O.rqs_fwd(x, *O.rqs_knots(params, -3.0, 3.0))
+    y, l = yd.to_numpy(), ld.to_numpy()
+    assert (np.abs(y - yr) <= 3 * tol(yr)).all() and (np.abs(l - lr) <= 3 * tol(lr)).all()
+    assert np.array_equal(xd.to_numpy(), x)                 # the input is not the kernels' in-place state
+    # only one output wanted: the other pointer NULL; same bits
+    y2 = DeviceArray((n,))
+    _lib.check(lib.nf_elementwise_apply(C.byref(desc), 0, xd.ptr, pd.ptr, n, y2.ptr, None, _lib.MEM_DEVICE))
+    assert np.array_equal(y2.to_numpy(), y)
+    l2 = np.empty(n, np.float32)
+    _lib.check(lib.nf_elementwise_apply(C.byref(desc), 0, x.ctypes.data_as(C.c_void_p), params.ctypes.data_as(C.c_void_p), n,
+                                        None, l2.ctypes.data_as(C.c_void_p), _lib.MEM_HOST))
+    assert np.array_equal(l2, l)
+    # inverse on the device round-trips
+    xb = DeviceArray((n,))
+    _lib.check(lib.nf_elementwise_apply(C.byref(desc), 1, yd.ptr, pd.ptr, n, xb.ptr, None, _lib.MEM_DEVICE))
+    inside = np.abs(x) < 2.9
+    assert np.abs(xb.to_numpy() - x)[inside].max() <= 2e-3
+    # n = 0 succeeds without touching anything; errors are NF_ERR_INVALID with a message
+    assert lib.nf_elementwise_apply(C.byref(desc), 0, None, None, 0, None, None, _lib.MEM_HOST) == 0
+    bad = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION, kind=7)
+    assert lib.nf_elementwise_apply(C.byref(bad), 0, xd.ptr, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE) == -1
+    bad = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION, kind=_lib.ELEM_RQS, rqs_bins=0, rqs_range_min=0.0, rqs_range_max=1.0,
+                               rqs_min_bin_size=1e-4, rqs_min_knot_slope=1e-4)
+    assert lib.nf_elementwise_apply(C.byref(bad), 0, xd.ptr, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE) == -1
+    bad = _lib.ElementwiseDesc(abi_version=_lib.NF_ABI_VERSION, kind=_lib.ELEM_RQS, rqs_bins=4, rqs_range_min=1.0, rqs_range_max=1.0,
+                               rqs_min_bin_size=1e-4, rqs_min_knot_slope=1e-4)
+    assert lib.nf_elementwise_apply(C.byref(bad), 0, xd.ptr, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE) == -1
+    assert b"range" in lib.nf_last_error()
+    assert lib.nf_elementwise_apply(C.byref(desc), 0, None, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE) == -1
+    assert lib.nf_elementwise_apply(None, 0, xd.ptr, pd.ptr, n, yd.ptr, ld.ptr, _lib.MEM_DEVICE) == -1

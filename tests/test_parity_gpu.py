@@ -1084,7 +1084,11 @@ def test_empty_batches_on_every_path(nfa, mode):
 
 
 # ---- what the GEMM kernels' buffer-descriptor range checks drop (general path, csrc/nf_generic.hip) -----------------
-@pytest.mark.parametrize("M,N,K,act", [(3001, 256, 36, 1), (130, 128, 44, 0), (257, 512, 784, 1), (1, 128, 32, 2)])
+@pytest.mark.parametrize("M,N,K,act", [(3001, 256, 36, 1), (130, 128, 44, 0), (257, 512, 784, 1), (1, 128, 32, 2),
+                                       # M <= 256, 64 <= K <= 2048, N <= 1024: gemm_small_m_kernel (round 4) -- whole
+                                       # tiles; a ragged row block, three column blocks and a last octet of 4 k; one row,
+                                       # a ragged column block; 255 rows, K = 2044 over sixteen waves
+                                       (128, 512, 512, 1), (33, 96, 68, 2), (1, 40, 64, 0), (255, 1000, 2044, 1)])
 def test_gemm_range_check_canary(nf_lib, M, N, K, act):
     """gemm_fast_kernel<FULL> stores C through one buffer descriptor over rows [m0, M) with a row's offset in the
     SCALAR offset, and reads a ragged last k tile of W / a ragged last row block of A past their ends, relying on
