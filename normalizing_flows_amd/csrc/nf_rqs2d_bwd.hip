@@ -147,6 +147,13 @@ __device__ __forceinline__ float half_sum(float x) {
   return x;
 }
 
+// Development: -DNF_RQSBWD_SKIP=<mask> builds a TIMING-ONLY kernel without some of its phases (wrong results, same remaining
+// instruction stream): 1 recompute of a2, 2 the parameter tile, 4 knots + bin + slope gather + the spline's gradient,
+// 8 the dW3 / db3 sums, 16 g2 = W3 dtheta (MFMAs + gather + mask), 32 g1 = W2 g2, 64 the first Linear, 128 dW2 + db2,
+// 256 the (db1, dW1) sums.  profiles/scratch/rqsbwd_phase_timing.sh; prices at 2^20 rows in EXPERIMENTS.md (round 4).
+#ifndef NF_RQSBWD_SKIP
+#define NF_RQSBWD_SKIP 0
+#endif
 constexpr int kWaves = 8;                // one workgroup per CU, two waves per SIMD
 constexpr int kGT = 32 * 65;             // one transposed tile [sample][unit], padded rows
 constexpr int kAopRow = 36;              // floats between factor rows (16-byte reads of four rows hit different banks)
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, bias1, 0, 0, 0);
       }
 #pragma unroll 8
-      for (int s = 1; s < 32; ++s) {
+      for (int s = 1; s < ((NF_RQSBWD_SKIP & 1) ? 1 : 32); ++s) {
         const float2 a = a2[s * 64];
         const float2 wb = w1b1[2 * s + h];
         const float b = __builtin_amdgcn_fmed3f(fmaf(c, wb.x, wb.y), 0.f, 1.f);
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
       {
         const f32x16 pb = lds_f32x16(L + oB3 + h * 16);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < ((NF_RQSBWD_SKIP & 2) ? 1 : 8); ++g) {
           const float4 a = a3[g * 64];
           const int m = g >> 2, r = (g & 3) * 4;
           out = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[m][r + 0], g == 0 ? pb : out, 0, 0, 0);
@@ -306,6 +313,16 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
         }
       }
 
+#if (NF_RQSBWD_SKIP & 4)
+      const int kb = lane & 7;
+      const float2* ws = reinterpret_cast<const float2*>(L + oWS) + h * (32 * rqs2d::kSlopePairs) + kb;
+      float d_l = out[0] * gy, d_r = out[1];
+      float dlg[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) dlg[k] = out[k] + t;
+      const float Gt = gy;
+      (void)cs_inv; (void)valid;
+#else
       // 3. knots, bin, the bin's slope logits -- the forward kernel's own steps (nf_rqs2d_h64.hip)
       float lg[K], knot[K + 1], size[K];
 #pragma unroll
@@ -399,13 +416,14 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
       }
       //    d loss / d c through the first Linear comes later; the transformed dim's gradient is done
       const float Gt = g_x;
+#endif
 
       // 4. dW3 and db3.  Batch A: the 2K bin-size logits' rows (half 0 writes widths, half 1 heights)
 #pragma unroll
       for (int k = 0; k < K; ++k) aop[(h * K + k) * kAopRow + i] = dlg[k];
       if (h == 0) crow[i] = c;
-      sample_sums_n<NGA>(D3a, f_ab, gT, lane);
-      if (lane < 2 * K) {
+      if ((NF_RQSBWD_SKIP & 8) == 0) sample_sums_n<NGA>(D3a, f_ab, gT, lane);
+      if ((NF_RQSBWD_SKIP & 8) == 0 && lane < 2 * K) {
         const float4* r4 = reinterpret_cast<const float4*>(aop + lane * kAopRow);
         float s = 0.f;
 #pragma unroll
@@ -419,8 +437,8 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
         const int k = h * 8 + k8;
         if (k < 4 * NGB) aop[k * kAopRow + i] = k == kb ? d_l : (k == kb + 1 ? d_r : 0.f);
       }
-      sample_sums_n<NGB>(D3b, f_ab, gT, lane);
-      if (lane <= K) {
+      if ((NF_RQSBWD_SKIP & 8) == 0) sample_sums_n<NGB>(D3b, f_ab, gT, lane);
+      if ((NF_RQSBWD_SKIP & 8) == 0 && lane <= K) {
         const float4* r4 = reinterpret_cast<const float4*>(aop + lane * kAopRow);
         float s = 0.f;
 #pragma unroll
@@ -433,11 +451,12 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { g2[0][r] = 0.f; g2[1][r] = 0.f; }
 #pragma unroll
-      for (int s = 0; s < K; ++s) {
+      for (int s = 0; s < ((NF_RQSBWD_SKIP & 16) ? 1 : K); ++s) {
         const float2 a = a3t[s * 64];
         g2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dlg[s], g2[0], 0, 0, 0);
         g2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dlg[s], g2[1], 0, 0, 0);
       }
+      if ((NF_RQSBWD_SKIP & 16) == 0)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -453,6 +472,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
       f32x16 g1[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) { g1[0][r] = 0.f; g1[1][r] = 0.f; }
+      if ((NF_RQSBWD_SKIP & 32) == 0)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -469,6 +489,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
 
       // 7. the first Linear: gz = g1 * [w1 c + b1 > 0] -> d loss / d c
       float gcm = 0.f;
+      if ((NF_RQSBWD_SKIP & 64) == 0)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
 
       // 8. dW2[k][j] += sum_i h1[k][i] g2[j][i]: samples on the MFMA's K dimension; between them db2
 #pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
+      for (int s = 0; s < ((NF_RQSBWD_SKIP & 128) ? 1 : 16); ++s) {
         const float ci = crow[2 * s + h];
         const float2 wb0 = w1b1[i], wb1 = w1b1[32 + i];
         const float a0 = __builtin_amdgcn_fmed3f(fmaf(ci, wb0.x, wb0.y), 0.f, 1.f);
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gTw[32 * m + 8 * (r >> 2) + (r & 3)] = g1[m][r];
-      {
+      if ((NF_RQSBWD_SKIP & 256) == 0) {
         f32x4 one[1] = {Dz};
         sample_sums_n<1>(one, f_1c, gT, lane);
         Dz = one[0];
