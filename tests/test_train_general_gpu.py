@@ -136,6 +136,16 @@ def test_spline_adam_steps_and_fused_kernel_follows(nfa):
     f.set_weights(spec.layers)
     assert_spline_log_prob(f.log_prob(x), spec, x, "after set_weights")
     check_grads(f, spec, x)
+    # ... and the restarted optimiser (moments, step count, both weight images refreshed on the device after every step)
+    # walks exactly like a fresh handle's
+    fresh = rqs_flow(nfa, spec)
+    for step in range(2):
+        xb = O.make_inputs("gaussian_blobs", 2048, seed=60 + step)
+        f.train_step(xb, opt)
+        fresh.train_step(xb, opt)
+    wf, wn = _flat(f.get_weights()), _flat(fresh.get_weights())
+    assert np.abs(wf - wn).max() <= 1e-7 * max(1.0, np.abs(wn).max())
+    assert np.array_equal(f.log_prob(x), fresh.log_prob(x))
 
 
 def test_spline_training_reduces_nll(nfa):
