@@ -504,7 +504,8 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
     const int tiles = gx * gy, ktiles = (K + FBK - 1) / FBK;
     if (tiles <= 128 && ktiles >= 8 && !switches().no_splitk) {
       NF_DYN_LDS(80 * 1024, &gemm_splitk_kernel);
-      int S = std::min((512 + tiles - 1) / tiles, ktiles / 4);
+      int S = std::min(std::max(1, 256 / tiles), ktiles / 4);   // one resident round of workgroups (77 tiles: 3 x 77 = 231 measured 549 us per MNIST-shape call against 575 with 4 x 77)
+      if (switches().splitk_s) S = std::max(1, std::min(switches().splitk_s, ktiles));
       const int Kc = ((ktiles + S - 1) / S) * FBK;
       S = (K + Kc - 1) / Kc;
       float* partial = splitk_scratch(stream, (size_t)S * M * N);
@@ -1368,7 +1369,8 @@ static int launch_gemm_splitk_rqs(const nf_flow_desc& d, const float* A, int lda
   if (rc.K != 4 && rc.K != 6 && rc.K != 8 && rc.K != 10 && rc.K != 12 && rc.K != 16) return NF_OK;
   if ((size_t)N * sizeof(float) > 60 * 1024) return NF_OK;   // a row's parameters must fit the spline kernel's LDS
   NF_DYN_LDS(80 * 1024, &gemm_splitk_kernel);
-  int S = std::min((512 + tiles - 1) / tiles, ktiles / 4);
+  int S = std::min(std::max(1, 256 / tiles), ktiles / 4);   // one resident round of workgroups (77 tiles: 3 x 77 = 231 measured 549 us per MNIST-shape call against 575 with 4 x 77)
+  if (switches().splitk_s) S = std::max(1, std::min(switches().splitk_s, ktiles));
   const int Kc = ((ktiles + S - 1) / S) * FBK;
   S = (K + Kc - 1) / Kc;
   float* partial = splitk_scratch(stream, (size_t)S * M * N);

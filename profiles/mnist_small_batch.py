@@ -17,8 +17,12 @@ for rows in [int(v) for v in os.environ.get("NF_MNIST_ROWS", "128,512,2048,8192"
     for _ in range(3):
         f.log_prob(x, out)
     f.synchronize()
+    import time
+    t0 = time.perf_counter()
     f.timer_start()
     for _ in range(20):
         f.log_prob(x, out)
+    t_enq = (time.perf_counter() - t0) / 20      # host time to ENQUEUE a call (nothing waited for yet)
     ms = f.timer_stop() / 20
-    print(f"rows {rows:6d}: {ms * 1e3:8.1f} us per log_prob call ({rows / ms / 1e3:7.3f} M evals/s)", flush=True)
+    print(f"rows {rows:6d}: {ms * 1e3:8.1f} us per log_prob call ({rows / ms / 1e3:7.3f} M evals/s); host enqueue "
+          f"{t_enq * 1e6:7.1f} us per call", flush=True)
