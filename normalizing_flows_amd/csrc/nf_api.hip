@@ -70,6 +70,7 @@ Switches Switches::from_env() {
   s.affine2d_no_msplit = on("NF_AFFINE2D_NO_MSPLIT");
   s.no_rqs2d_bwd = on("NF_NO_RQS2D_BWD");
   s.no_small_m = on("NF_NO_SMALL_M");
+  s.no_compact_l1 = on("NF_NO_COMPACT_L1");
   auto pair = [](const char* name, int* out) {
     if (const char* e = getenv(name)) {
       int t = 0, w = 0;

@@ -1192,6 +1192,23 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
   NF_HIP(hipMemcpy(d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   host_weights.swap(host);
+  // compact first Linear (masked kinds, wide events; see nf_internal.h)
+  w1c = false;
+  if (d_w1c) { hipFree(d_w1c); d_w1c = nullptr; }
+  if (d.kind != NF_KIND_AFFINE_SPLIT && d.event_dim >= 128 && !switches().no_compact_l1) {
+    w1c_k[0] = (((d.event_dim + 1) / 2) + 3) & ~3;
+    w1c_k[1] = ((d.event_dim / 2) + 3) & ~3;
+    w1c_off.assign(d.num_layers, 0);
+    size_t total = 0;
+    for (int l = 0; l < d.num_layers; ++l) {
+      w1c_off[l] = total;
+      total += (size_t)w1c_k[(d.first_mask_parity + l) & 1] * linears[(size_t)l * nlin].N;
+    }
+    NF_HIP(hipMalloc(&d_w1c, total * sizeof(float)));
+    w1c = true;
+    NF_TRY(refresh_w1c(nullptr));
+    NF_HIP(hipStreamSynchronize(nullptr));
+  }
   // K5: the last Linear of a spline layer through gemm_rqs_kernel
   k5 = false;
   if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
@@ -1275,6 +1292,8 @@ void Plan::release() {
   if (d_weights) { hipFree(d_weights); d_weights = nullptr; }
   if (d_wk5) { hipFree(d_wk5); d_wk5 = nullptr; }
   k5 = false;
+  if (d_w1c) { hipFree(d_w1c); d_w1c = nullptr; }
+  w1c = false;
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
   hipFree(bwd.d_small_partials);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
@@ -1290,14 +1309,16 @@ int Plan::ensure_scratch(long long rows) {
   // per row: two activation ping-pong buffers + the conditioner's output; up to 4 GiB of the
   // 288 GB so that even the 784-D flow walks 2^16 rows in one chunk (big M keeps the GEMMs of the
   // narrow hidden layers at full occupancy)
-  const size_t per_row = ((size_t)2 * act_width + param_width + (k5 ? k5_npad / 128 : 0)) * sizeof(float);
+  const size_t per_row = ((size_t)2 * act_width + param_width + (k5 ? k5_npad / 128 : 0) +
+                          (w1c ? std::max(w1c_k[0], w1c_k[1]) : 0)) * sizeof(float);
   long long cap = (long long)(((size_t)4 << 30) / per_row);
   cap = std::max<long long>(128, cap / 128 * 128);
   const long long want = std::min(rows, cap);
   if (want <= scratch_rows) return NF_OK;
   if (d_scratch) { hipFree(d_scratch); d_scratch = nullptr; scratch_rows = 0; }
-  NF_HIP(hipMalloc(&d_scratch, per_row * (size_t)want));
+  NF_HIP(hipMalloc(&d_scratch, per_row * (size_t)want + 16));
   scratch_rows = want;
+  xc_off = ((((size_t)2 * act_width + param_width + (k5 ? k5_npad / 128 : 0)) * (size_t)want) + 3) & ~(size_t)3;
   return NF_OK;
 }
 
@@ -1347,6 +1368,50 @@ int launch_transform(const nf_flow_desc& d, float* yc, float* ldc, const float* 
     }
   }
   NF_HIP(hipGetLastError());
+  return NF_OK;
+}
+
+// ---- compact first Linear of wide masked flows (Plan::w1c) --------------------------------------------------------
+// xc[row][j] = y[row][2 j + parity] for j < kc (the dims the layer passes through and shows its conditioner), 0 up to kpad
+__global__ __launch_bounds__(256) void gather_pass_dims_kernel(const float* __restrict__ y, int D, float* __restrict__ xc,
+                                                               int kc, int kpad, long long rows, int parity) {
+  const long long total = rows * (long long)kpad;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / kpad;
+    const int j = (int)(e - row * kpad);
+    xc[e] = j < kc ? y[row * D + 2 * j + parity] : 0.f;
+  }
+}
+// the same for D % 4 == 0 (kc = D / 2, no padding): one 16-byte load and one 8-byte store per thread
+__global__ __launch_bounds__(256) void gather_pass_dims4_kernel(const float4* __restrict__ y4, float2* __restrict__ xc2,
+                                                                long long quads, int parity) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < quads; e += (long long)gridDim.x * 256) {
+    const float4 v = y4[e];
+    xc2[e] = parity ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+  }
+}
+// wc[j][n] = W[2 j + parity][n] (the rows d_weights keeps non-zero), zero rows up to kpad
+__global__ __launch_bounds__(256) void gather_live_rows_kernel(const float* __restrict__ W, float* __restrict__ wc, int N,
+                                                               int kc, int kpad, int parity) {
+  const long long total = (long long)kpad * N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e / N), n = (int)(e - (long long)j * N);
+    wc[e] = j < kc ? W[(size_t)(2 * j + parity) * N + n] : 0.f;
+  }
+}
+
+int Plan::refresh_w1c(hipStream_t stream) {
+  const int nlin = desc.num_hidden + 1;
+  for (int l = 0; l < desc.num_layers; ++l) {
+    const Linear& L = linears[(size_t)l * nlin];
+    const int par = (desc.first_mask_parity + l) & 1;
+    const int kc = par == 0 ? (desc.event_dim + 1) / 2 : desc.event_dim / 2;
+    const long long total = (long long)w1c_k[par] * L.N;
+    hipLaunchKernelGGL(gather_live_rows_kernel, dim3((unsigned)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
+                       stream, d_weights + L.w_off, d_w1c + w1c_off[l], L.N, kc, w1c_k[par], par);
+  }
+  NF_HIP(hipGetLastError());
+  w1c_stale = false;
   return NF_OK;
 }
 
@@ -1409,6 +1474,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
     NF_TRY(refresh_k5(stream));
     k5_stale = false;
   }
+  if (w1c && w1c_stale && !record_tape) NF_TRY(refresh_w1c(stream));
   const int act = d.activation == NF_ACT_RELU ? 1 : 2;
   const RqsConst rc = make_rqs_const(d);
   for (long long r0 = 0; r0 < io.rows; r0 += scratch_rows) {
@@ -1486,7 +1552,22 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         if (x3 && d_wx3 && !few_tiles && gemm_x3_applicable(a, lda, L.N, L.K))
           NF_TRY(launch_gemm_x3(a, lda, d_wx3 + L.x3_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
                                 j == nlin - 1 ? 0 : act, stream));
-        else
+        else if (j == 0 && w1c && !record_tape && n >= 1024 && a == yc && nlin > 1) {
+          // wide masked flow, large batch: the pass-through dims gathered into a dense matrix, the live rows of W1
+          const int kpad = w1c_k[par], kc = par == 0 ? (D + 1) / 2 : D / 2;
+          float* xc = d_scratch + xc_off;
+          if ((D & 3) == 0 && kpad == D / 2) {
+            const long long quads = n * (long long)(D / 4);
+            hipLaunchKernelGGL(gather_pass_dims4_kernel, dim3((unsigned)std::min<long long>(16384, (quads + 255) / 256)),
+                               dim3(256), 0, stream, reinterpret_cast<const float4*>(yc), reinterpret_cast<float2*>(xc),
+                               quads, par);
+          } else {
+            const long long total = n * (long long)kpad;
+            hipLaunchKernelGGL(gather_pass_dims_kernel, dim3((unsigned)std::min<long long>(16384, (total + 255) / 256)),
+                               dim3(256), 0, stream, yc, D, xc, kc, kpad, n, par);
+          }
+          NF_TRY(launch_gemm(xc, kpad, d_w1c + w1c_off[l], d_weights + L.b_off, dst, L.N, (int)n, L.N, kpad, act, stream));
+        } else
           NF_TRY(launch_gemm(a, lda, d_weights + L.w_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
                              j == nlin - 1 ? 0 : act, stream));
         a = dst;

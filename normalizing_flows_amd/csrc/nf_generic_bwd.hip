@@ -518,6 +518,7 @@ int Plan::refresh_after_step(hipStream_t stream) {
                      d_weights, b.d_wT, static_cast<const TransposeJob*>(b.d_jobs));
   NF_HIP(hipGetLastError());
   k5_stale = true;  // the training walk does not use the fused last Linear: re-laid when an evaluation asks for it
+  w1c_stale = true; // nor the compact first Linear
   return NF_OK;
 }
 

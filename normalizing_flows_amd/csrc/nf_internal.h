@@ -46,6 +46,7 @@ struct Switches {
   bool no_mlp_small = false, no_mlp_small_bwd = false, affine2d_no_msplit = false;
   bool no_rqs2d_bwd = false;             // NF_NO_RQS2D_BWD: the fused 2-D spline flow trains through the general plan
   bool no_small_m = false;               // NF_NO_SMALL_M: the general path's small-batch (M <= 256) kernels off
+  bool no_compact_l1 = false;            // NF_NO_COMPACT_L1: the first Linear of wide masked flows over its whole (half-zero) k range
   int affine2d_tune[2] = {0, 0}, affine2d_x3_tune[2] = {0, 0}, rqs2d_tune[2] = {0, 0}, rqs2d_x3_tune[2] = {0, 0};  // T, WAVES; 0 = unset
   int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
   int splitk_s = 0;                           // NF_SPLITK_S (development): number of k splits of the few-tile GEMMs
@@ -337,6 +338,17 @@ struct Plan {
   int k5_npad = 0;
   std::vector<size_t> k5_x3_off;     // per layer: the K5-layout split image inside d_wx3 (bf16x3 mode)
   bool k5_stale = false;             // an optimiser step changed d_weights: re-lay before the next fused walk
+  // Masked kinds with a wide event (the 784-D flow): `where(mask, x, 0) @ W1` multiplies half of its k range by zero
+  // rows.  Evaluation walks of large batches gather the pass-through dims of x into a dense [rows, w1c_k] matrix first
+  // and multiply it with the live rows of W1 only (the same products in the same order: exact zeros leave a sum's
+  // bits alone) -- half the first Linear's MFMA work for one streaming pass over x.
+  bool w1c = false;
+  int w1c_k[2] = {0, 0};             // compact k (pass-through dims, padded to a multiple of 4) for pass parity 0 / 1
+  float* d_w1c = nullptr;            // per layer: [w1c_k[parity of the layer]][N]
+  std::vector<size_t> w1c_off;
+  bool w1c_stale = false;
+  size_t xc_off = 0;                 // floats into d_scratch where the gathered matrix starts (16-byte aligned)
+  int refresh_w1c(hipStream_t stream);
   int refresh_k5(hipStream_t stream);  // from d_weights (after build; after optimiser steps on the next evaluation walk)
   bool record_tape = false;          // walk() fills bwd.d_tape (set around the training forward)
   int ensure_tape(long long rows);
