@@ -1083,6 +1083,45 @@ def test_empty_batches_on_every_path(nfa, mode):
         assert np.isfinite(f.log_prob(one)).all()
 
 
+@pytest.mark.parametrize("kind,D,hidden,rows", [("rqs", 784, (512, 512), 4224), ("rqs", 131, (128, 160), 1500),
+                                                ("affine", 200, (256,), 1027)])
+def test_wide_masked_flows_first_linear_on_live_dims(nfa, monkeypatch, kind, D, hidden, rows):
+    """Large batches of wide masked flows (event size >= 128, >= 1024 rows) gather the pass-through dims and multiply
+    them with the live rows of the first Linear only (Plan::w1c) instead of walking the whole, half-zero k range:
+    the same products in the same order, so the SAME BITS as the plain form (NF_NO_COMPACT_L1=1) wherever the GEMM does
+    not split K (4224 rows of the 784-D shape: 132 tiles; with <= 128 tiles the two forms split 784 and 392 differently
+    and agree to rounding only), both walks; odd D
+    (66 / 65 live dims, padded to 68), both mask parities over three layers, ragged row counts; and against the
+    oracle."""
+    if kind == "rqs":
+        spec = O.make_rqs_spec(3, event_size=D, hidden=hidden, num_bins=8, range_min=0.0, range_max=1.0, base="uniform01",
+                               final_std=0.1, first_parity=D & 1)
+        make = lambda: rqs_flow(nfa, spec, D & 1)
+        x = np.random.default_rng(D).uniform(0.01, 0.99, (rows, D)).astype(np.float32)
+    else:
+        spec = O.make_affine_spec(3, event_size=D, hidden=hidden, final_std=0.02)
+        make = lambda: affine_flow(nfa, spec)
+        x = (np.random.default_rng(D).standard_normal((rows, D)) * 1.2).astype(np.float32)
+    from normalizing_flows_amd import _lib
+    f = make()
+    assert f.kernel_name == "generic_gemm"
+    lp = f.log_prob(x)
+    z, ld = f.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    monkeypatch.setenv("NF_NO_COMPACT_L1", "1")
+    g = make()
+    monkeypatch.delenv("NF_NO_COMPACT_L1")
+    assert np.array_equal(lp, g.log_prob(x))
+    z2, ld2 = g.chain_apply(_lib.DIR_CHAIN_FORWARD, x)
+    assert np.array_equal(z, z2) and np.array_equal(ld, ld2)
+    xb, _ = f.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    xb2, _ = g.chain_apply(_lib.DIR_CHAIN_INVERSE, z)
+    assert np.array_equal(xb, xb2)
+    sub = slice(0, 96)
+    ref = O.log_prob(spec, x[sub])
+    m = np.isfinite(ref)
+    assert (np.abs(lp[sub][m].astype(np.float64) - ref[m]) <= 2e-5 * np.maximum(1.0, np.abs(ref[m]))).all()
+
+
 # ---- what the GEMM kernels' buffer-descriptor range checks drop (general path, csrc/nf_generic.hip) -----------------
 @pytest.mark.parametrize("M,N,K,act", [(3001, 256, 36, 1), (130, 128, 44, 0), (257, 512, 784, 1), (1, 128, 32, 2),
                                        # M <= 256, 64 <= K <= 2048, N <= 1024: gemm_small_m_kernel (round 4) -- whole
