@@ -534,18 +534,19 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
       if (h == 0 && valid) p.G[idx] = G_out;
     }
 
-    // one partial gradient per workgroup: the waves lay theirs out in the scratch (dead by now), two at a time, and
-    // they are added in wave order
-    static_assert(2 * kPartialFloats <= kWaves * kWaveScratch, "staging of two partials");
+    // one partial gradient per workgroup: the waves lay theirs out in LDS (all of it dead by now), FOUR at a time --
+    // three in the scratch, the fourth over the layer's image -- and they are added in wave order (two rounds; two
+    // partials per round cost four rounds of ~3 us per layer)
+    static_assert(3 * kPartialFloats <= kWaves * kWaveScratch && kPartialFloats <= kImageFloats, "staging of four partials");
     constexpr int kPer = (kPartialFloats + kWaves * 64 - 1) / (kWaves * 64);
     float total[kPer];
 #pragma unroll
     for (int e = 0; e < kPer; ++e) total[e] = 0.f;
 #pragma unroll
-    for (int round = 0; round < kWaves / 2; ++round) {
+    for (int round = 0; round < kWaves / 4; ++round) {
       __syncthreads();
-      if ((wave >> 1) == round) {
-        float* P = scratch + (wave & 1) * kPartialFloats;
+      if ((wave >> 2) == round) {
+        float* P = (wave & 3) == 3 ? lds : scratch + (wave & 3) * kPartialFloats;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -577,7 +578,8 @@ __global__ __launch_bounds__(kWaves * 64) void chain_kernel(Params p) {
 #pragma unroll
       for (int e = 0; e < kPer; ++e) {
         const int q = tid + e * kWaves * 64;
-        if (q < kPartialFloats) total[e] = (total[e] + scratch[q]) + scratch[kPartialFloats + q];
+        if (q < kPartialFloats)
+          total[e] = (((total[e] + scratch[q]) + scratch[kPartialFloats + q]) + scratch[2 * kPartialFloats + q]) + lds[q];
       }
     }
     float* outp = p.partials + ((size_t)layer * gridDim.x + blockIdx.x) * kPartialFloats;
