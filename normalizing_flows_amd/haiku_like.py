@@ -31,6 +31,7 @@ training step is `training.update` (nf_train_step), see INTEGRATION.md.
 from __future__ import annotations
 
 import hashlib
+import weakref
 from typing import Callable, Dict, List, Mapping, Optional, Tuple
 
 import numpy as np
@@ -85,10 +86,38 @@ except ImportError:                       # pragma: no cover - blake2b: ~1 GB/s,
         return hashlib.blake2b(buf, digest_size=16).digest()
 
 
+_FROZEN_DIGESTS: dict = {}   # id(array) -> (weakref to it, key): arrays nothing can write to are hashed once
+
+
+def _immutable(a) -> bool:
+    """True when no NumPy handle can write to a's bytes: a itself and every ndarray it is a view of are read-only
+    (np.asarray of a jax.Array is such an array; a read-only VIEW of a writable array is not)."""
+    b = a
+    while isinstance(b, np.ndarray):
+        if b.flags.writeable:
+            return False
+        b = b.base
+    return True
+
+
 def _array_key(a: np.ndarray) -> tuple:
     """Shape, dtype and a digest of EVERY byte: an optimiser step, a reassigned array and an in-place edit of a
     single entry all change it (a sparse sample of large arrays, as an earlier version took, lets such an edit
-    evaluate stale device weights silently)."""
+    evaluate stale device weights silently).  The digest of an array that CANNOT change (read-only all the way down:
+    what np.asarray gives for the reference's jax parameters) is computed once per array object; writable arrays are
+    hashed on every call (30 ms per apply for the 351 MB of the MNIST-shape flow with xxh3: INTEGRATION.md)."""
+    if isinstance(a, np.ndarray) and _immutable(a):
+        hit = _FROZEN_DIGESTS.get(id(a))
+        if hit is not None and hit[0]() is a:
+            return hit[1]
+        c = np.ascontiguousarray(a)
+        key = (c.shape, c.dtype.num, _digest(memoryview(c).cast("B")))
+        try:
+            ident = id(a)
+            _FROZEN_DIGESTS[ident] = (weakref.ref(a, lambda _r, ident=ident: _FROZEN_DIGESTS.pop(ident, None)), key)
+        except TypeError:      # (an ndarray subclass without weak references: hash it every time)
+            pass
+        return key
     a = np.ascontiguousarray(a)
     return (a.shape, a.dtype.num, _digest(memoryview(a).cast("B")))   # (str(dtype) alone cost 3 us per array)
 

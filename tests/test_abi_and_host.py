@@ -225,6 +225,37 @@ def test_haiku_like_transform_init_names_and_errors():
     assert hk.params_key(big) != k0
 
 
+def test_haiku_like_hashes_immutable_arrays_once(monkeypatch):
+    """The content key of a parameter array is a digest of every byte, taken on every apply -- except for arrays that
+    nothing can write to (read-only all the way down the view chain: np.asarray of the reference's jax parameters):
+    those are hashed once per array object.  A read-only VIEW of a writable array is not such an array."""
+    import normalizing_flows_amd.haiku_like as hk
+    calls = []
+    real = hk._digest
+    monkeypatch.setattr(hk, "_digest", lambda buf: (calls.append(1), real(buf))[1])
+    frozen = np.arange(1000, dtype=np.float32)
+    frozen.flags.writeable = False
+    k0 = hk._array_key(frozen)
+    assert hk._array_key(frozen) == k0 and hk._array_key(frozen) == k0 and len(calls) == 1
+    other = np.arange(1000, dtype=np.float32) + 1
+    other.flags.writeable = False
+    assert hk._array_key(other) != k0 and len(calls) == 2          # another object: its own digest
+    live = np.arange(1000, dtype=np.float32)
+    k1 = hk._array_key(live)
+    live[3] = -1.0
+    assert hk._array_key(live) != k1 and len(calls) == 4           # writable: hashed every time, the edit is seen
+    view = live[:500]
+    view.flags.writeable = False                                   # read-only view, writable base
+    k2 = hk._array_key(view)
+    live[7] = 9.0
+    assert hk._array_key(view) != k2 and len(calls) == 6
+    n = len(hk._FROZEN_DIGESTS)
+    del frozen, other
+    import gc
+    gc.collect()
+    assert len(hk._FROZEN_DIGESTS) <= n - 2                        # entries leave with their arrays
+
+
 def test_haiku_like_function_building_two_models():
     """A transformed function may build two flows of ONE architecture (and evaluate the first before it builds the
     second).  The tree is validated by a dry run that evaluates nothing, so a bad tree raises ValueError without a
