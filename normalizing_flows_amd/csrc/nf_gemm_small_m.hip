@@ -115,8 +115,9 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m_kernel(const f
 // one workgroup's share of W -- K x 32 NT floats -- does not sit on one CU's memory pipe (the data-gradient product of
 // the MNIST shape's last Linear, K = 9800, keeps the split-K form), 16-byte rows of A -- and N <= 1024: every operand
 // element is used by 32 MFMA rows or columns only (no LDS tile shares it further), which is the right trade for the
-// hidden Linears (11.3 us per launch against 13.4 + 5.1 for slabs + reduction, rocprofv3 kernel trace at batch 128,
-// where ~4.5 us of every dependent launch is the boundary itself) and the wrong one for the MNIST shape's last Linear
+// hidden Linears (11.3 us per launch against 13.4 + 5.1 for slabs + reduction in the rocprofv3 kernel trace at batch 128,
+// whose timestamps charge every kernel >= 4.2 us; outside the profiler 8.9 us in a dependent chain, 1.7 us of it MFMA time
+// on the 64 CUs the grid covers: profiles/microbench/small_m_chain.hip) and the wrong one for the MNIST shape's last Linear
 // (N = 9800: 157 MB of L2 -> CU traffic, 46-55 us against 24 + 7 for the 128 x 128 tiles' slabs; measured, NT = 1 / 4).
 bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K) {
   return !switches().no_small_m && M >= 1 && M <= 256 && K >= 64 && K <= 2048 && N >= 32 &&
