@@ -75,18 +75,25 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m_kernel(const f
       for (int j = 0; j < 4; ++j) b[buf][c][j] = wp[(size_t)(kc + j) * N];
     }
   };
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < kSmallMChunk; ++c) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].x, b[buf][c][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].y, b[buf][c][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].z, b[buf][c][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].w, b[buf][c][3], acc, 0, 0, 0);
+    }
+  };
+  // two stages per trip: the buffer index is then a compile-time constant (indexed at run time the operand arrays went
+  // to scratch memory, 144 bytes per lane)
   if (o_begin < o_end) {
     fetch(0, o_begin);
-    int buf = 0;
-    for (int o = o_begin; o < o_end; o += kSmallMChunk, buf ^= 1) {
-      if (o + kSmallMChunk < o_end) fetch(buf ^ 1, o + kSmallMChunk);
-#pragma unroll
-      for (int c = 0; c < kSmallMChunk; ++c) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].x, b[buf][c][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].y, b[buf][c][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].z, b[buf][c][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][c].w, b[buf][c][3], acc, 0, 0, 0);
-      }
+    for (int o = o_begin; o < o_end; o += 2 * kSmallMChunk) {
+      const bool second = o + kSmallMChunk < o_end;   // wave-uniform
+      if (second) fetch(1, o + kSmallMChunk);
+      multiply(0);
+      if (o + 2 * kSmallMChunk < o_end) fetch(0, o + 2 * kSmallMChunk);
+      if (second) multiply(1);
     }
   }
 #pragma unroll
@@ -111,14 +118,101 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m_kernel(const f
   }
 }
 
+// The same product on 16 x 16 tiles (v_mfma_f32_16x16x4_f32): four times the workgroups of the 32 x 32 form -- [128, 512]
+// x [512, 512] covers all 256 CUs instead of 64, a wave's share of K is 8 MFMAs of 32 cycles instead of 16 of 64, a
+// workgroup's operands are 64 KB instead of 128 KB.  (The launch boundary itself is <= 2.9 us of these figures.)
+// Lane (m = lane & 15, kq = lane >> 4) of a wave holds, per group of 16 k, A[row m][16 g + 4 kq .. + 3] (one 16-byte load)
+// and W[16 g + 4 kq + j][column m] for j < 4; MFMA j of the group multiplies k slot kq with k = 16 g + 4 kq + j on both
+// sides.  Result register r of lane l: row 4 (l >> 4) + r, column l & 15.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kSmallM16Groups = 2;   // groups of 16 k per software-pipeline stage
+
+__global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m16_kernel(const float* __restrict__ A, int lda,
+                                                                          const float* __restrict__ W,
+                                                                          const float* __restrict__ bias,
+                                                                          float* __restrict__ Cm, int ldc, int M, int N,
+                                                                          int K, int act, const float* __restrict__ aux) {
+  __shared__ float red[kSmallMWaves][4][64];   // every wave's raw 16 x 16 tile (16 KB)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int groups = (K + 15) >> 4;
+  const int per = (groups + kSmallMWaves - 1) / kSmallMWaves;
+  const int g_begin = wave * per;
+  const int g_end = min(groups, g_begin + per);
+  const int row = min(m0 + i, M - 1);
+  const int col = min(n0 + i, N - 1);
+  const float* ap = A + (size_t)row * lda;
+  const float* wp = W + col;
+
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  float4 a[2][kSmallM16Groups];
+  float b[2][kSmallM16Groups][4];
+  auto fetch = [&](int buf, int g0) {
+#pragma unroll
+    for (int c = 0; c < kSmallM16Groups; ++c) {
+      const int g = g0 + c;
+      const int k = 16 * min(g, groups - 1) + 4 * kq;
+      const bool live = g < g_end && k < K;
+      const int kc = min(k, K - 4);
+      float4 v = *reinterpret_cast<const float4*>(ap + kc);
+      if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      a[buf][c] = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[buf][c][j] = wp[(size_t)(kc + j) * N];
+    }
+  };
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < kSmallM16Groups; ++c) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][c].x, b[buf][c][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][c].y, b[buf][c][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][c].z, b[buf][c][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][c].w, b[buf][c][3], acc, 0, 0, 0);
+    }
+  };
+  // two stages per trip so that the buffer index is a constant (a run-time index would put the operands in scratch)
+  if (g_begin < g_end) {
+    fetch(0, g_begin);
+    for (int g = g_begin; g < g_end; g += 2 * kSmallM16Groups) {
+      const bool second = g + kSmallM16Groups < g_end;   // wave-uniform
+      if (second) fetch(1, g + kSmallM16Groups);
+      multiply(0);
+      if (g + 2 * kSmallM16Groups < g_end) fetch(0, g + 2 * kSmallM16Groups);
+      if (second) multiply(1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (tid < 256) {   // 256 outputs: thread (r, l) adds the sixteen waves' tiles in order
+    const int r = tid >> 6, l = tid & 63;
+    const int orow = m0 + 4 * (l >> 4) + r, ocol = n0 + (l & 15);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kSmallMWaves; ++w) v += red[w][r][l];
+    if (orow < M && ocol < N) {
+      v += bias[ocol];
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+      else if (act >= 3) v = aux[(size_t)orow * ldc + ocol] > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
+      Cm[(size_t)orow * ldc + ocol] = v;
+    }
+  }
+}
+
 // Shapes the kernel takes: few rows, a k range that sixteen waves can share without starving and short enough that
 // one workgroup's share of W -- K x 32 NT floats -- does not sit on one CU's memory pipe (the data-gradient product of
 // the MNIST shape's last Linear, K = 9800, keeps the split-K form), 16-byte rows of A -- and N <= 1024: every operand
 // element is used by 32 MFMA rows or columns only (no LDS tile shares it further), which is the right trade for the
-// hidden Linears (11.3 us per launch against 13.4 + 5.1 for slabs + reduction in the rocprofv3 kernel trace at batch 128,
-// whose timestamps charge every kernel >= 4.2 us; outside the profiler 8.9 us in a dependent chain, 1.7 us of it MFMA time
-// on the 64 CUs the grid covers: profiles/microbench/small_m_chain.hip) and the wrong one for the MNIST shape's last Linear
-// (N = 9800: 157 MB of L2 -> CU traffic, 46-55 us against 24 + 7 for the 128 x 128 tiles' slabs; measured, NT = 1 / 4).
+// hidden Linears (in a dependent chain outside the profiler, profiles/microbench/small_m_chain.hip: 3.7 us per
+// [128, 512] x [512, 512] launch and 4.6 us at K = 784 on 16 x 16 tiles, 6.7 / 10.7 us on 32 x 32 tiles; slabs + reduction
+// took 13.4 + 5.1 us in the kernel trace) and the wrong one for the MNIST shape's last Linear (N = 9800: 157 MB of
+// L2 -> CU traffic; NF_SMALL_M_NT=8 routes it here: the 8-layer log_prob call at batch 128 takes 542 us against 369).
+// Until round 4's last day both kernels indexed their operand double buffer with a run-time variable, which put the
+// buffer in scratch memory (144 bytes per lane): 8.9 / 14.8 us per launch on 32 x 32 tiles, 28 us on 16 x 16 tiles.
 bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K) {
   return !switches().no_small_m && M >= 1 && M <= 256 && K >= 64 && K <= 2048 && N >= 32 &&
          (N <= 1024 || switches().small_m_nt != 0) && (lda & 3) == 0 && (K & 3) == 0 &&
@@ -127,6 +221,13 @@ bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K) {
 
 int launch_gemm_small_m(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N,
                         int K, int act, hipStream_t stream, const float* aux) {
+  // small enough for one resident round of 16 x 16 tiles: all 256 CUs take part (NF_SMALL_M_NT set: the 32 x 32 forms)
+  if ((long long)((N + 15) / 16) * ((M + 15) / 16) <= 512 && (switches().small_m_nt == 0 || switches().small_m_nt == 8)) {
+    hipLaunchKernelGGL(gemm_small_m16_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(kSmallMWaves * 64), 0, stream, A, lda, W,
+                       bias, Cm, ldc, M, N, K, act, aux);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   const int gy = (M + 31) / 32;
   // wider column blocks once the grid fills the chip anyway: A's rows are then fetched by fewer workgroups
   int NT = 1;
