@@ -466,11 +466,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 
 // grow-only scratch for the split-K slabs, one per (host thread, stream): handles are driven from one thread each,
 // and two handles of one thread run on different streams
-static float* splitk_scratch(hipStream_t stream, size_t floats) {
-  struct Slot { hipStream_t stream; float* ptr; size_t floats; };
+// (use 0: the slabs; use 1: the log-det partials of nf_small_m_rqs.hip, which live across a walk's layers)
+static float* splitk_scratch(hipStream_t stream, size_t floats, int use = 0) {
+  struct Slot { hipStream_t stream; int use; float* ptr; size_t floats; };
   static thread_local std::vector<Slot> slots;
   for (Slot& sl : slots)
-    if (sl.stream == stream) {
+    if (sl.stream == stream && sl.use == use) {
       if (sl.floats >= floats) return sl.ptr;
       hipStreamSynchronize(stream);
       hipFree(sl.ptr);
@@ -480,7 +481,7 @@ static float* splitk_scratch(hipStream_t stream, size_t floats) {
       sl.floats = floats;
       return sl.ptr;
     }
-  Slot sl{stream, nullptr, 0};
+  Slot sl{stream, use, nullptr, 0};
   if (hipMalloc(&sl.ptr, floats * sizeof(float)) != hipSuccess) return nullptr;
   sl.floats = floats;
   slots.push_back(sl);
@@ -861,7 +862,44 @@ __global__ __launch_bounds__(256) void k5_layout_kernel(const float* __restrict_
   }
 }
 
+// Few rows, many blocks (the small-batch spline layers leave layers x column groups of them: 448 at the MNIST shape):
+// one thread per row walks 28 dependent rounds of loads (10 us at 128 rows).  Here sixteen waves share a row's blocks:
+// wave w adds blocks [w c, (w + 1) c) of 64 rows (lane = row: coalesced), the sixteen sums are added in wave order.
+__global__ __launch_bounds__(1024) void ld_reduce_few_rows_kernel(const float* __restrict__ ldpart, int nblocks, int rows,
+                                                                  float* __restrict__ ld) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
+  const int chunk = (nblocks + 15) / 16;
+  const int b0 = wave * chunk, b1 = min(nblocks, b0 + chunk);
+  float s = 0.f;
+  if (r < rows) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ldpart[(size_t)(b + j) * rows + r];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; b < b1; ++b) s += ldpart[(size_t)b * rows + r];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && r < rows) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane];
+    ld[r] += t;
+  }
+}
+
 static int launch_ld_reduce(const float* ldpart, int nblocks, int M, float* ld, hipStream_t stream) {
+  if (M <= 1024 && nblocks >= 64) {
+    hipLaunchKernelGGL(ld_reduce_few_rows_kernel, dim3((M + 63) / 64), dim3(1024), 0, stream, ldpart, nblocks, M, ld);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   hipLaunchKernelGGL(ld_reduce_kernel, dim3((unsigned)std::min<long long>(4096, ((long long)M + 255) / 256)), dim3(256), 0,
                      stream, ldpart, nblocks, (long long)M, ld);
   NF_HIP(hipGetLastError());
@@ -1192,6 +1230,8 @@ int Plan::build(const nf_flow_desc& d, const float* packed) {
   NF_HIP(hipMalloc(&d_weights, host.size() * sizeof(float)));
   NF_HIP(hipMemcpy(d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   host_weights.swap(host);
+  if (d_wsmr) { hipFree(d_wsmr); d_wsmr = nullptr; }   // the small-batch copy of the last Linears: laid again on first use
+  wsmr_stale = true;
   // compact first Linear (masked kinds, wide events; see nf_internal.h)
   w1c = false;
   if (d_w1c) { hipFree(d_w1c); d_w1c = nullptr; }
@@ -1294,6 +1334,7 @@ void Plan::release() {
   k5 = false;
   if (d_w1c) { hipFree(d_w1c); d_w1c = nullptr; }
   w1c = false;
+  if (d_wsmr) { hipFree(d_wsmr); d_wsmr = nullptr; }
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
   hipFree(bwd.d_small_partials);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
@@ -1415,6 +1456,29 @@ int Plan::refresh_w1c(hipStream_t stream) {
   return NF_OK;
 }
 
+int Plan::ensure_wsmr(hipStream_t stream) {
+  const int nlin = desc.num_hidden + 1;
+  if (d_wsmr == nullptr) {
+    wsmr_off.assign(desc.num_layers, 0);
+    size_t total = 0;
+    for (int l = 0; l < desc.num_layers; ++l) {
+      const Linear& L = linears[(size_t)l * nlin + nlin - 1];
+      wsmr_off[l] = total;
+      total += small_m_rqs_packed_floats(L.N, L.K, desc.rqs_bins);
+    }
+    NF_HIP(hipMalloc(&d_wsmr, std::max<size_t>(total, 4) * sizeof(float)));
+    wsmr_stale = true;
+  }
+  if (wsmr_stale) {
+    for (int l = 0; l < desc.num_layers; ++l) {
+      const Linear& L = linears[(size_t)l * nlin + nlin - 1];
+      NF_TRY(launch_small_m_rqs_pack(d_weights + L.w_off, d_wsmr + wsmr_off[l], L.N, L.K, desc.rqs_bins, stream));
+    }
+    wsmr_stale = false;
+  }
+  return NF_OK;
+}
+
 // The last Linear of a spline layer at a small batch: split-K slabs (the test is launch_gemm's), added up inside the
 // spline kernel instead of by a reduction launch.  *done = false: not this shape -- the caller takes the plain route.
 static int launch_gemm_splitk_rqs(const nf_flow_desc& d, const float* A, int lda, const float* W, const float* bias,
@@ -1483,6 +1547,8 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
     float* ldc = ld + r0;
     float* buf[3] = {d_scratch, d_scratch + (size_t)scratch_rows * act_width,
                      d_scratch + (size_t)2 * scratch_rows * act_width};
+    int ld_parts = 0;                // [column group][row] log-det partials waiting to be added into ldc
+    float* ld_parts_at = nullptr;
     for (int li = 0; li < nlay; ++li) {
       const int l = io.descending ? io.layer_end - 1 - li : io.layer_begin + li;
       const int par = (d.first_mask_parity + l) & 1;  // masked: pass-through parity; split: flip
@@ -1535,6 +1601,24 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
           fused_transform = true;
           break;
         }
+        if (j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3) && n <= 256) {
+          // small batch, float32: the Linear and the spline in one launch on every CU (nf_small_m_rqs.hip); the
+          // log-det partials of all layers are added after the last one
+          const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
+          const int cgs = small_m_rqs_groups(a, lda, (int)n, L.N, L.K, Dt, rc.K);
+          if (cgs > 0) {
+            const int cg_max = (D + 1) / 2;   // >= any layer's column groups
+            float* ldp = splitk_scratch(stream, (size_t)nlay * cg_max * n, 1);
+            if (ldp == nullptr) { set_error("out of device memory for the log-det partials"); return NF_ERR_HIP; }
+            NF_TRY(ensure_wsmr(stream));
+            NF_TRY(launch_small_m_rqs(a, lda, d_wsmr + wsmr_off[l], d_weights + L.b_off, yc, ldp + (size_t)ld_parts * n,
+                                      nullptr, (int)n, L.N, L.K, D, par, io.inverse_op, rc, stream));
+            ld_parts += cgs;
+            ld_parts_at = ldp;
+            fused_transform = true;
+            break;
+          }
+        }
         if (j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3)) {
           // small batch, float32: the slabs of the split-K product go straight into the spline kernel
           bool done = false;
@@ -1577,6 +1661,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         NF_TRY(launch_transform(d, yc, ldc, a /* the last Linear's output */, n, par, io.inverse_op, rc, stream));
       NF_HIP(hipGetLastError());
     }
+    if (ld_parts > 0) NF_TRY(launch_ld_reduce(ld_parts_at, ld_parts, (int)n, ldc, stream));
   }
   return NF_OK;
 }

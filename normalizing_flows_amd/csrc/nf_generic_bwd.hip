@@ -519,6 +519,7 @@ int Plan::refresh_after_step(hipStream_t stream) {
   NF_HIP(hipGetLastError());
   k5_stale = true;  // the training walk does not use the fused last Linear: re-laid when an evaluation asks for it
   w1c_stale = true; // nor the compact first Linear
+  wsmr_stale = true; // nor the small-batch copy of the last Linears
   return NF_OK;
 }
 

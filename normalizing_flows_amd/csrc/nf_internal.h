@@ -50,6 +50,7 @@ struct Switches {
   int affine2d_tune[2] = {0, 0}, affine2d_x3_tune[2] = {0, 0}, rqs2d_tune[2] = {0, 0}, rqs2d_x3_tune[2] = {0, 0};  // T, WAVES; 0 = unset
   int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
   int splitk_s = 0;                           // NF_SPLITK_S (development): number of k splits of the few-tile GEMMs
+  bool no_small_m_rqs = false;                // NF_NO_SMALL_M_RQS: split-K slabs + rqs_rows_kernel at small batches
   int small_m_nt = 0;                         // NF_SMALL_M_NT = 1 | 2 | 4: column blocks per workgroup of gemm_small_m_kernel (any N); 8: any N, automatic form
   long long inline_tail_rows = 0;             // NF_INLINE_TAIL_LG (clamped to [0, 40]); 0 = unset
   static Switches from_env();
@@ -289,6 +290,14 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
 bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K);
 int launch_gemm_small_m(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N,
                         int K, int act, hipStream_t stream, const float* aux);
+// nf_small_m_rqs.hip: a masked spline layer's last Linear + the spline at M <= 256 rows in one launch; the log-dets
+// arrive as [column group][row] partials (small_m_rqs_groups() of them per layer; 0: not a shape for that kernel)
+int small_m_rqs_groups(const float* A, int lda, int M, int N, int Kdim, int Dt, int bins);
+size_t small_m_rqs_packed_floats(int N, int Kdim, int bins);   // W re-laid in that kernel's operand order
+int launch_small_m_rqs_pack(const float* W, float* Wp, int N, int Kdim, int bins, hipStream_t stream);
+int launch_small_m_rqs(const float* A, int lda, const float* Wp, const float* bias, float* y, float* ldpart,
+                       float* theta_out, int M, int N, int Kdim, int D, int par, int inverse_op, const RqsConst& rc,
+                       hipStream_t stream);
 int launch_transform(const nf_flow_desc& d, float* y, float* ld, const float* params, long long n, int par,
                      int inverse_op, const RqsConst& rc, hipStream_t stream);
 // stand-alone ScalarAffine on explicit per-element parameters (nf_elementwise_apply); y / ld may be null
@@ -347,6 +356,13 @@ struct Plan {
   float* d_w1c = nullptr;            // per layer: [w1c_k[parity of the layer]][N]
   std::vector<size_t> w1c_off;
   bool w1c_stale = false;
+  // Small batches (M <= 256) of a masked spline flow: the last Linears re-laid in the operand order of
+  // linear_rqs_small_m_kernel (nf_small_m_rqs.hip) -- a second copy of those weights, made by the first walk that
+  // needs it
+  float* d_wsmr = nullptr;
+  std::vector<size_t> wsmr_off;      // per layer, floats
+  bool wsmr_stale = true;
+  int ensure_wsmr(hipStream_t stream);
   size_t xc_off = 0;                 // floats into d_scratch where the gathered matrix starts (16-byte aligned)
   int refresh_w1c(hipStream_t stream);
   int refresh_k5(hipStream_t stream);  // from d_weights (after build; after optimiser steps on the next evaluation walk)
