@@ -894,6 +894,47 @@ def test_general_path_small_batches_split_k(nfa, monkeypatch, kind, D, hidden, r
     assert (np.abs(whole.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * noise)).all()
 
 
+@pytest.mark.parametrize("D,hidden,K,rows", [(300, (64,), 4, 77), (500, (128, 256), 12, 100), (257, (272,), 6, 256),
+                                             (400, (64,), 16, 100), (400, (64, 256), 10, 64), (784, (512, 512), 8, 33)])
+def test_small_batch_last_linear_and_spline_in_one_launch(nfa, monkeypatch, D, hidden, K, rows):
+    """nf_small_m_rqs.hip (masked spline flow, <= 256 rows, last hidden size % 16 == 0, enough column groups to fill the
+    chip; bin counts 6 / 8 / 10 / 12 with a last hidden size below 256 keep the GEMM with the spline epilogue, whose
+    tiles are short in k there): every bin count it is built for, rows that do not fill the last 32-row block, an odd event size (the two
+    parities transform 128 / 129 dims), a last column group with fewer dims than the others -- density evaluation and
+    the generative walk against the float64 oracle, and against the same flow through the split-K route
+    (NF_NO_SMALL_M_RQS)."""
+    spec = O.make_rqs_spec(3, event_size=D, hidden=hidden, num_bins=K, range_min=-3.0, range_max=3.0, final_std=0.05)
+    x = (np.random.default_rng(D + rows).standard_normal((rows, D)) * 1.2).astype(np.float32)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "generic_gemm"
+    ref, z = assert_spline_forward(f, spec, x, "one-launch last Linear + spline")
+    assert_spline_inverse(f, spec, z, "one-launch last Linear + spline, inverse")
+    got = f.log_prob(x)
+    assert np.array_equal(got, f.log_prob(x))        # run-to-run identical
+    monkeypatch.setenv("NF_NO_SMALL_M_RQS", "1")
+    other = rqs_flow(nfa, spec).log_prob(x)
+    noise = f32_noise(spec, lambda c, v: O.log_prob(c, v, np.float32), ref, x)
+    assert (np.abs(other.astype(np.float64) - got) <= 2 * np.maximum(tol(ref), SPLINE_F32_FACTOR * noise)).all()
+    assert not np.array_equal(other, got) or rows * D < 4096   # the switch does select another summation order
+
+
+def test_small_batch_weight_copy_follows_the_weights(nfa):
+    """The operand-ordered copy of the last Linears (made by the first small-batch walk) is re-laid after an optimiser
+    step and after set_weights: log_prob of 64 rows equals that of a fresh handle on the same weights."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(2, event_size=400, hidden=(64, 64), num_bins=8, range_min=-3.0, range_max=3.0, final_std=0.05)
+    x = (np.random.default_rng(5).standard_normal((64, 400)) * 1.2).astype(np.float32)
+    f = rqs_flow(nfa, spec)
+    before = f.log_prob(x)
+    f.train_step(x, training.adam(1e-2))
+    after = f.log_prob(x)
+    assert not np.array_equal(before, after)
+    fresh = nfa.CouplingFlow(f.config, f.get_weights())
+    assert np.array_equal(after, fresh.log_prob(x))
+    f.set_weights(spec.layers)
+    assert np.array_equal(before, f.log_prob(x))
+
+
 # ------------------------------------------------------------------ backward pass / training step
 def _flat(layers):
     return np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()])
