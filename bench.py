@@ -638,8 +638,8 @@ def next_rows(args, lib, _lib, flow, densities, make_conditioner, measure, block
     line("d1-d2", "log_prob, MNIST shape of src/maf_mnist.py: 8 layers, 784-D, batch 128 (the reference's evaluation batch)",
          f.kernel_name, 128, wall, ev_ms, walls, "evals/s",
          hbm(1, live * 4, ev_ms, "per call: the live weights streamed once; 4 dependent launches per layer (three one-launch "
-             "Linears of gemm_small_m_kernel, the split-K last Linear whose slabs the spline kernel adds): latency chains, "
-             "DESIGN.md 3.8"))
+             "Linears of gemm_small_m16_kernel, the last Linear + spline in linear_rqs_small_m_kernel): launch boundaries "
+             "and what one CU can pull, DESIGN.md 3.8"))
     f.close()
     lpm.free()
 

@@ -5,24 +5,32 @@
 // What this replaces: gemm_splitk_kernel (128 x 128 tiles, K split three ways: 231 workgroups, 20.5 us per launch at the
 // MNIST shape [128, 512] x [512, 9800], its 15 MB of slabs through HBM) + rqs_rows_kernel adding the slabs (one workgroup
 // per row: 128 of 256 CUs, five dependent rounds of loads, 10.2 us): 30.7 of the 45 us a layer of that flow took at batch
-// 128 once the hidden Linears were one launch each (rocprofv3 kernel trace, round 4).  The product is 1.28 GFLOP --
-// 8.2 us of the whole chip's f32 MFMA rate -- so unlike the hidden Linears this one is bound by MFMA issue, and the
-// design question is how to keep 256 CUs' matrix cores busy on a 128-row problem:
+// 128 once the hidden Linears were one launch each (rocprofv3 kernel trace, round 4).  This kernel: 24.4 us per launch
+// in a chain over the eight layers' weights (profiles/microbench/small_m_rqs_clocks.hip); the 8-layer log_prob call at
+// batch 128 went from 369 to 296 us.  The product is 1.28 GFLOP -- 8.2 us of the whole chip's f32 MFMA rate:
 //
 //   * one workgroup = 32 rows x DW transformed dims (DW (3K + 1) <= 176 columns = 11 MFMA column tiles; K = 8: 7 dims,
 //     175 columns), so [128, 9800] is 4 x 56 = 224 workgroups -- one resident round, 87 % of the CUs, every MFMA column
 //     but one per workgroup useful;
 //   * its EIGHT waves split Kdim between them (Kdim = 512: four groups of 16 k each); a wave holds all 22 result tiles
-//     (16 x 16, v_mfma_f32_16x16x4_f32: 88 accumulator registers) and streams its operands from global memory straight
-//     into MFMA operand registers, double-buffered by hand (buffer indices are compile-time constants: a run-time index
-//     sends the arrays to scratch memory) -- every element of A and W is loaded ONCE per workgroup, and each W element
-//     feeds two MFMAs;
+//     (16 x 16, v_mfma_f32_16x16x4_f32: 88 accumulator registers) and loads its operands from global memory straight
+//     into MFMA operand registers -- every element of A and W is loaded ONCE per workgroup, each W element feeds two
+//     MFMAs;
+//   * W is read from a copy laid out in exactly that operand order (pack_kernel; Plan::ensure_wsmr makes it on the
+//     first small-batch walk and again after the weights change): a workgroup's share is one contiguous 360 KB block,
+//     a wave-load 1 KB, a lane's four k of one column tile one 16-byte load.  Read in place the share is 512 pieces of
+//     700 bytes, 39 KB apart: 28-31 us per launch;
 //   * the waves' tiles are added through LDS in wave order (run-to-run identical), one row tile at a time (8 x 11 KB),
 //     bias added last, and the 32 x DW (3K + 1) parameters stay in LDS for the spline: one thread per (row, dim),
 //     rqs_eval_reg on y in place (the same arithmetic as every other spline kernel here: nf_rqs_math.h);
 //   * a row's log-dets of the workgroup's dims are added in dim order into ldpart[column group][row]; the caller adds
 //     the column groups of ALL layers of a walk in order with one ld_reduce launch at the end (a per-layer reduction
 //     launch would cost more than it adds).
+// Where the 24 us go (shader-clock stamps of every wave, same microbenchmark): loads + MFMAs 13.5 us (a group's loads
+// land after 2.3 / 2.3 / 1.1 / 1.1 us, its 88 MFMAs take 1.4-2.0 us next to the SIMD's other wave), waiting for the
+// workgroup's slowest wave + the cross-wave sum 4.4 us, spline 1.3 us, launch boundary 2.4 us.  The loads are bound by
+// what one CU can pull (422 KB per workgroup: the four row blocks re-read W, the 56 column groups re-read A), the
+// same with the weights resident in L2 (one matrix instead of eight: 24.1 us) -- not by HBM.
 // Lane (i = lane & 15, kq = lane >> 4) holds, per group of 16 k, A[row i][16 g + 4 kq .. + 3] per row tile and
 // W[16 g + 4 kq + j][column i] per column tile; MFMA j multiplies k = 16 g + 4 kq + j.  Result register r of lane l:
 // row 4 (l >> 4) + r, column l & 15.
@@ -42,7 +50,7 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #define NF_SMR_SKIP 0
 #endif
 #ifndef NF_SMR_LOOP
-#define NF_SMR_LOOP 3
+#define NF_SMR_LOOP 0
 #endif
 // -DNF_SMR_CLOCKS (profiles/microbench/small_m_rqs_clocks.hip): theta_out is a debug buffer, every wave leaves the shader
 // clock at six program points and the 100 MHz wall clock at entry and exit
@@ -162,27 +170,14 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
       acc[1][ct] = SMR_MFMA(a[buf][1].w, b[buf][ct].w, acc[1][ct], 0, 0, 0);
     }
   };
-  // ONE copy of the loads and of the 88 MFMAs, run once per group: buffer 1 is where loads land, buffer 0 what the
-  // MFMAs read, 52 register moves in between.  (Unrolled over two landing buffers the loop body ran ONCE per wave --
-  // 1300 instructions of straight-line code, each cache line of it fetched from L2 while the matrix cores waited:
-  // the MFMAs cost 16.5 us per launch against 9.8 us at their issue rate.)  sched_barrier: the machine scheduler
-  // otherwise sinks the next group's loads in between the MFMAs to save registers (~7 loads in flight instead of 46).
-#if NF_SMR_LOOP == 1
-  if (g_begin < g_end) {
-    fetch(1, g_begin);
-    for (int g = g_begin; g < g_end; ++g) {
-      a[0][0] = a[1][0];
-      a[0][1] = a[1][1];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) b[0][ct] = b[1][ct];
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(1, min(g + 1, g_end - 1));   // (the last trip re-reads its own group: no branch around the loads)
-      __builtin_amdgcn_sched_barrier(0);
-      multiply(0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#elif NF_SMR_LOOP == 2
+  // The k loop: a group's loads, then its 88 MFMAs -- no overlap between them.  What bounds this phase is how many bytes a
+  // CU can pull (a workgroup reads 358 KB of W and 64 KB of A; 13 us at ~40 GB/s per CU, between the L2-hit and the
+  // Infinity-Cache rates of MI355X_MICROARCH.md's gather table), not latency: with the next group's loads in flight under
+  // the MFMAs (NF_SMR_LOOP=2: two landing buffers, scheduling barriers so that the loads stay ahead of the MFMAs) a
+  // wave's first group lands after 6.8 us instead of 2.3 and the launch takes 25.5 us against 24.3 (shader-clock stamps,
+  // profiles/microbench/small_m_rqs_clocks.hip).  The buffer index is a compile-time constant in both forms (a run-time
+  // index sends the operand arrays to scratch memory).
+#if NF_SMR_LOOP == 2
   if (g_begin < g_end) {
     int g = g_begin;
     fetch(0, g);
@@ -210,32 +205,26 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
       multiply(0);
     }
   }
-#elif NF_SMR_LOOP == 4
-  // instrumentation: no overlap at all, one copy of the code
+#else
   {
+#ifdef NF_SMR_CLOCKS
     int slot = 8;
+#endif
     for (int g = g_begin; g < g_end; ++g) {
       fetch(0, g);
+#ifdef NF_SMR_CLOCKS
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
       if (slot < 16) SMR_STAMP(slot);
       ++slot;
       __builtin_amdgcn_sched_barrier(0);
+#endif
       multiply(0);
+#ifdef NF_SMR_CLOCKS
       __builtin_amdgcn_sched_barrier(0);
       if (slot < 16) SMR_STAMP(slot);
       ++slot;
-    }
-  }
-#else
-  if (g_begin < g_end) {
-    fetch(0, g_begin);
-    for (int g = g_begin; g < g_end; g += 2) {
-      const bool second = g + 1 < g_end;   // wave-uniform
-      if (second) fetch(1, g + 1);
-      multiply(0);
-      if (g + 2 < g_end) fetch(0, g + 2);
-      if (second) multiply(1);
+#endif
     }
   }
 #endif

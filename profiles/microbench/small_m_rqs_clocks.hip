@@ -3,7 +3,7 @@
 // six program points and the 100 MHz wall clock at entry and exit.  Launched in a chain over eight weight matrices (the
 // eight layers' 20 MB each), like the flow does.  Prints microseconds per launch on the stream, the shader clock the
 // two counters imply, and the mean / max over waves of each phase.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DNF_SMR_CLOCKS -DNF_SMR_LOOP=3 -I../../include -I../../normalizing_flows_amd/csrc \
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DNF_SMR_CLOCKS [-DNF_SMR_LOOP=2] -I../../include -I../../normalizing_flows_amd/csrc \
 //     small_m_rqs_clocks.hip -L../../normalizing_flows_amd -lnf_hip -Wl,-rpath,'$ORIGIN/../../normalizing_flows_amd' -o small_m_rqs_clocks
 // (own names: the library holds the same kernel, and one host stub cannot stand for two device functions)
 #define linear_rqs_small_m_kernel linear_rqs_small_m_kernel_clocks
@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
     }
   }
 #endif
-#if NF_SMR_LOOP == 4
+#if NF_SMR_LOOP == 0
   const char* inner[8] = {"group 0: loads landed", "group 0: MFMAs issued", "group 1: loads landed", "group 1: MFMAs issued",
                           "group 2: loads landed", "group 2: MFMAs issued", "group 3: loads landed", "group 3: MFMAs issued"};
   for (int p = 0; p < 8; ++p) {
