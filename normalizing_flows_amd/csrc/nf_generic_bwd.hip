@@ -389,6 +389,79 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
   }
 }
 
+// The same product for FEW rows and a WIDE result (the last Linear of the 784-D flow at batch 128: [513, 9800] over 128
+// rows).  tn_partial_kernel's 32 x 32 tiles read 32 KB of operands per 4 KB of result with one 4-byte-per-lane load per
+// MFMA operand: 164 MB of L2 -> CU traffic and 2,600 wave-loads per CU, 37 us per launch against 8 us of MFMA time, a
+// quarter of the training step at batch 128 (EXPERIMENTS 3.8).  Here: one workgroup = 64 x 128 of the result, eight
+// waves with one 32 x 32 tile each; 64 rows of both operands at a time are staged through LDS with 16-byte loads (48 KB:
+// three workgroups per CU, so one's staging runs under another's MFMAs), MFMA operands are 4-byte LDS reads (lane =
+// column: conflict-free).  66 MB of L2 -> CU traffic, a quarter of the vector-memory instructions.  Every result
+// element belongs to one lane: added straight into the gradient.
+constexpr int kTnChunk = 64;
+__global__ __launch_bounds__(512) void tn_few_rows_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, int rows, int K, int N,
+                                                          int tiles_n, float* __restrict__ grad_w,
+                                                          float* __restrict__ grad_b) {
+  __shared__ __attribute__((aligned(16))) float As[kTnChunk][64];
+  __shared__ __attribute__((aligned(16))) float Bs[kTnChunk][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int kb = (blockIdx.x / tiles_n) * 64, nb = (blockIdx.x % tiles_n) * 128;
+  const int kt = 32 * (wave & 1), nt = 32 * (wave >> 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int m0 = 0; m0 < rows; m0 += kTnChunk) {
+    if (m0) __syncthreads();
+    // A: 64 rows x 16 quads, B: 64 rows x 32 quads; a quad past the edge is assembled element by element
+    // (column K of [A, 1] is the column of ones that makes row K of the product the bias gradient)
+    for (int q = tid; q < kTnChunk * 16; q += 512) {
+      const int r = q >> 4, c = (q & 15) * 4;
+      const int row = m0 + r, col = kb + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows) {
+        const float* src = A + (size_t)row * lda + col;
+        if (col + 3 < K) v = *reinterpret_cast<const float4*>(src);
+        else {
+          v.x = col < K ? src[0] : (col == K ? 1.f : 0.f);
+          v.y = col + 1 < K ? src[1] : (col + 1 == K ? 1.f : 0.f);
+          v.z = col + 2 < K ? src[2] : (col + 2 == K ? 1.f : 0.f);
+          v.w = col + 3 < K ? src[3] : (col + 3 == K ? 1.f : 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(&As[r][c]) = v;
+    }
+    for (int q = tid; q < kTnChunk * 32; q += 512) {
+      const int r = q >> 5, c = (q & 31) * 4;
+      const int row = m0 + r, col = nb + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows) {
+        const float* src = B + (size_t)row * ldb + col;
+        if (col + 3 < N) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (col < N) v.x = src[0];
+          if (col + 1 < N) v.y = src[1];
+          if (col + 2 < N) v.z = src[2];
+        }
+      }
+      *reinterpret_cast<float4*>(&Bs[r][c]) = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int u = 0; u < kTnChunk / 2; ++u)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * u + h][kt + i], Bs[2 * u + h][nt + i], acc, 0, 0, 0);
+  }
+  const int nn = nb + nt + i;
+  if (nn < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = kb + kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (kk < K) grad_w[(size_t)kk * N + nn] += acc[r];
+      else if (kk == K) grad_b[nn] += acc[r];
+    }
+  }
+}
+
 // 64 outputs per workgroup; its four waves each add every fourth chunk slab (in order), LDS joins the
 // four partial sums in a fixed order.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int nchunks, size_t kn,
@@ -427,7 +500,13 @@ static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long 
   long long chunk_rows = (rows + nchunks - 1) / nchunks;
   chunk_rows = (chunk_rows + 1) & ~1LL;
   nchunks = (int)((rows + chunk_rows - 1) / chunk_rows);
-  if (nchunks == 1) {
+  const int wide_k = (K + 1 + 63) / 64, wide_n = (N + 127) / 128;
+  const bool quads = (lda & 3) == 0 && (ldb & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  if (nchunks == 1 && rows <= 256 && quads && (long long)wide_k * wide_n >= 256 && !switches().no_tn_few_rows) {
+    hipLaunchKernelGGL(tn_few_rows_kernel, dim3(wide_k * wide_n), dim3(512), 0, stream, A, lda, B, ldb, (int)rows, K, N,
+                       wide_n, grad_w, grad_b);
+  } else if (nchunks == 1) {
     hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, 1), dim3(256), 0, stream, A, lda, B, ldb, partials,
                        rows, chunk_rows, K, N, tiles_n, grad_w, grad_b);
   } else {

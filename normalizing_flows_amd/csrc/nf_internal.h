@@ -50,6 +50,7 @@ struct Switches {
   int affine2d_tune[2] = {0, 0}, affine2d_x3_tune[2] = {0, 0}, rqs2d_tune[2] = {0, 0}, rqs2d_x3_tune[2] = {0, 0};  // T, WAVES; 0 = unset
   int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
   int splitk_s = 0;                           // NF_SPLITK_S (development): number of k splits of the few-tile GEMMs
+  bool no_tn_few_rows = false;                // NF_NO_TN_FEW_ROWS: 32 x 32 tiles for every weight gradient
   bool no_small_m_rqs = false;                // NF_NO_SMALL_M_RQS: split-K slabs + rqs_rows_kernel at small batches
   int small_m_nt = 0;                         // NF_SMALL_M_NT = 1 | 2 | 4: column blocks per workgroup of gemm_small_m_kernel (any N); 8: any N, automatic form
   long long inline_tail_rows = 0;             // NF_INLINE_TAIL_LG (clamped to [0, 40]); 0 = unset

@@ -95,9 +95,23 @@ def test_general_gradient_matches_the_fused_backward(nfa):
     assert np.abs(_flat(g_a) - _flat(g_b)).max() <= 1e-12
 
 
-def test_mnist_shape_gradient(nfa):
-    """BASELINE.json configs[4] shapes (784-D, MLP 512x3, K = 8 on [0, 1], Uniform base), 2 layers, 64 rows."""
-    x = O.make_inputs("mnist_like", 64)
+@pytest.mark.parametrize("rows", [64, 73])
+def test_mnist_shape_gradient(nfa, monkeypatch, rows):
+    """BASELINE.json configs[4] shapes (784-D, MLP 512x3, K = 8 on [0, 1], Uniform base), 2 layers, 64 rows; 73 rows: a
+    ragged second pass of the last Linear's LDS-staged weight gradient (tn_few_rows_kernel), and the same gradient
+    through the 32 x 32 tiles (NF_NO_TN_FEW_ROWS)."""
+    if rows == 73:
+        x = O.make_inputs("mnist_like", rows)
+        spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0, range_max=1.0,
+                               base="uniform01", final_std=0.1)
+        _, g_wide = rqs_flow(nfa, spec).nll_grad(x)
+        monkeypatch.setenv("NF_NO_TN_FEW_ROWS", "1")
+        _, g_tiles = rqs_flow(nfa, spec).nll_grad(x)
+        scale = np.abs(_flat(g_tiles)).max()
+        assert np.abs(_flat(g_wide) - _flat(g_tiles)).max() <= 2e-5 * scale
+        assert not np.array_equal(_flat(g_wide), _flat(g_tiles))   # the switch does select another kernel
+        monkeypatch.delenv("NF_NO_TN_FEW_ROWS")
+    x = O.make_inputs("mnist_like", rows)
     spec = O.make_rqs_spec(2, event_size=784, hidden=(512, 512, 512), num_bins=8, range_min=0.0, range_max=1.0,
                            base="uniform01", final_std=0.1)
     f = rqs_flow(nfa, spec)
