@@ -695,6 +695,7 @@ struct SlabSum {
   const float* bias = nullptr;
   int S = 0;
   size_t stride = 0;   // floats between slabs
+  float* theta_out = nullptr;   // training: the summed parameters [rows, N] also go here (the backward walk reads them)
 };
 template <int K, int INV>
 __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, float* __restrict__ ld,
@@ -742,8 +743,15 @@ __global__ __launch_bounds__(256) void rqs_rows_kernel(float* __restrict__ y, fl
             v1.x += t1[u].x; v1.y += t1[u].y; v1.z += t1[u].z; v1.w += t1[u].w;
           }
         }
-        reinterpret_cast<float4*>(sm)[q0] = make_float4(v0.x + c0.x, v0.y + c0.y, v0.z + c0.z, v0.w + c0.w);
-        if (two) reinterpret_cast<float4*>(sm)[q1] = make_float4(v1.x + c1.x, v1.y + c1.y, v1.z + c1.z, v1.w + c1.w);
+        const float4 w0 = make_float4(v0.x + c0.x, v0.y + c0.y, v0.z + c0.z, v0.w + c0.w);
+        const float4 w1 = make_float4(v1.x + c1.x, v1.y + c1.y, v1.z + c1.z, v1.w + c1.w);
+        reinterpret_cast<float4*>(sm)[q0] = w0;
+        if (two) reinterpret_cast<float4*>(sm)[q1] = w1;
+        if (slabs.theta_out != nullptr) {
+          float4* t4 = reinterpret_cast<float4*>(slabs.theta_out + (size_t)row0 * N);
+          t4[q0] = w0;
+          if (two) t4[q1] = w1;
+        }
       }
     } else if (((size_t)row0 * Dt * P & 3) == 0) {
       for (int q = tid * 4; q < nfl; q += 1024) {
@@ -1483,7 +1491,7 @@ int Plan::ensure_wsmr(hipStream_t stream) {
 // spline kernel instead of by a reduction launch.  *done = false: not this shape -- the caller takes the plain route.
 static int launch_gemm_splitk_rqs(const nf_flow_desc& d, const float* A, int lda, const float* W, const float* bias,
                                   int M, int N, int K, float* yc, float* ldc, int par, int inverse_op, const RqsConst& rc,
-                                  hipStream_t stream, bool* done) {
+                                  hipStream_t stream, bool* done, float* theta_out = nullptr) {
   *done = false;
   const int D = d.event_dim;
   const int Dt = par == 0 ? D / 2 : (D + 1) / 2;
@@ -1512,6 +1520,7 @@ static int launch_gemm_splitk_rqs(const nf_flow_desc& d, const float* A, int lda
   ss.bias = bias;
   ss.S = S;
   ss.stride = (size_t)M * N;
+  ss.theta_out = theta_out;
   bool ok = false;
   switch (rc.K) {
     case 4: ok = launch_rqs_rows<4>(yc, ldc, nullptr, M, D, par, inverse_op, rc, stream, ss); break;
@@ -1619,11 +1628,13 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
             break;
           }
         }
-        if (j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3)) {
-          // small batch, float32: the slabs of the split-K product go straight into the spline kernel
+        if (j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !(x3 && d_wx3)) {
+          // small batch, float32: the slabs of the split-K product go straight into the spline kernel (training: which
+          // also leaves the summed parameters where the backward walk looks for them)
           bool done = false;
+          float* theta = record_tape ? bwd.d_acts + bwd.act_off[(size_t)l * nlin + j] + (size_t)r0 * L.N : nullptr;
           NF_TRY(launch_gemm_splitk_rqs(d, a, lda, d_weights + L.w_off, d_weights + L.b_off, (int)n, L.N, L.K, yc, ldc, par,
-                                        io.inverse_op, rc, stream, &done));
+                                        io.inverse_op, rc, stream, &done, theta));
           if (done) { fused_transform = true; break; }
         }
         float* dst = buf[j == nlin - 1 ? 2 : (j & 1)];
