@@ -1168,7 +1168,10 @@ def test_wide_masked_flows_first_linear_on_live_dims(nfa, monkeypatch, kind, D, 
                                        # M <= 256, 64 <= K <= 2048, N <= 1024: gemm_small_m_kernel (round 4) -- whole
                                        # tiles; a ragged row block, three column blocks and a last octet of 4 k; one row,
                                        # a ragged column block; 255 rows, K = 2044 over sixteen waves
-                                       (128, 512, 512, 1), (33, 96, 68, 2), (1, 40, 64, 0), (255, 1000, 2044, 1)])
+                                       (128, 512, 512, 1), (33, 96, 68, 2), (1, 40, 64, 0), (255, 1000, 2044, 1),
+                                       # the 16 x 16 form (at most 512 small tiles): exactly 512 of them with K = 2048;
+                                       # ragged rows, a ragged column tile and a last group of 4 k
+                                       (256, 512, 2048, 2), (200, 500, 100, 1)])
 def test_gemm_range_check_canary(nf_lib, M, N, K, act):
     """gemm_fast_kernel<FULL> stores C through one buffer descriptor over rows [m0, M) with a row's offset in the
     SCALAR offset, and reads a ragged last k tile of W / a ragged last row block of A past their ends, relying on
