@@ -84,6 +84,7 @@ Switches Switches::from_env() {
   if (const char* e = getenv("NF_SPLIT2D_SAMPLES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) s.split2d_samples = v; }
   if (const char* e = getenv("NF_SPLIT2D_GRID")) { const int v = atoi(e); if (v >= 1 && v <= kBlockSumCap) s.split2d_grid = v; }
   s.no_small_m_rqs = on("NF_NO_SMALL_M_RQS");
+  s.no_bwd_overlap = on("NF_NO_BWD_OVERLAP");
   s.no_tn_few_rows = on("NF_NO_TN_FEW_ROWS");
   if (const char* e = getenv("NF_SMALL_M_NT")) s.small_m_nt = atoi(e);
   if (const char* e = getenv("NF_SPLITK_S")) { const int v = atoi(e); s.splitk_s = v < 0 ? 0 : (v > 64 ? 64 : v); }

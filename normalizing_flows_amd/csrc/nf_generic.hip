@@ -1346,6 +1346,9 @@ void Plan::release() {
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
   hipFree(bwd.d_small_partials);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
+  if (bwd.side) { hipStreamSynchronize(bwd.side); hipStreamDestroy(bwd.side); }
+  for (hipEvent_t e : bwd.ev) hipEventDestroy(e);
+  hipFree(bwd.d_layer_grads);
   bwd = Backward();
   if (d_wx3) { hipFree(d_wx3); d_wx3 = nullptr; }
   host_weights.clear();

@@ -665,13 +665,35 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
     NF_HIP(hipMalloc(&b.d_scratch, per_row * (size_t)want));
     b.scratch_rows = want;
   }
+  // Small batches: a layer's weight-gradient products (a third of the step at batch 128 of the 784-D flow, and nothing
+  // in the chain waits for them) go to a second stream once the layer's data gradients are out; each layer keeps its own
+  // d theta and hidden gradients for that.
+  const bool narrow_bwd = b.d_small_partials != nullptr && mlp_small_bwd_applicable(&linears[0], nlin, D);
+  const bool overlap = rows <= 512 && rows <= want && !narrow_bwd && !switches().no_bwd_overlap;
+  const size_t layer_floats = (size_t)param_width + (size_t)nh * gwidth;   // per row
+  if (overlap) {
+    if (b.side == nullptr) NF_HIP(hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking));
+    while ((int)b.ev.size() < d.num_layers + 1) {
+      hipEvent_t e;
+      NF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      b.ev.push_back(e);
+    }
+    if (rows > b.layer_grad_rows) {
+      NF_HIP(hipStreamSynchronize(b.side));
+      hipFree(b.d_layer_grads);
+      b.d_layer_grads = nullptr;
+      b.layer_grad_rows = 0;
+      NF_HIP(hipMalloc(&b.d_layer_grads, layer_floats * (size_t)rows * d.num_layers * sizeof(float)));
+      b.layer_grad_rows = rows;
+    }
+  }
   NF_HIP(hipMemsetAsync(b.d_grad, 0, b.n_weights * sizeof(float), stream));
   if (grad_canon) NF_HIP(hipMemsetAsync(grad_canon, 0, weight_count * sizeof(float), stream));
   hipLaunchKernelGGL(base_grad_kernel, dim3(grid_for(rows * D)), dim3(256), 0, stream, v, g, rows * D, d.base, inv_n);
 
   const long long R = b.scratch_rows;
-  float* dth = b.d_scratch;                                    // [R][param_width]
-  float* ga = dth + (size_t)R * param_width;                   // [R][gwidth]
+  float* const dth0 = b.d_scratch;                             // [R][param_width]
+  float* ga = dth0 + (size_t)R * param_width;                  // [R][gwidth]
   float* gb = ga + (size_t)R * gwidth;
   for (long long r0 = 0; r0 < rows; r0 += R) {
     const long long n = std::min(R, rows - r0);
@@ -683,6 +705,8 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       // the recorded outputs of this layer's Linears: hidden activations, then theta
       auto recorded = [&](int j) { return b.d_acts + b.act_off[(size_t)l * nlin + j] + (size_t)r0 * Ls[j].N; };
       const float* th = recorded(nlin - 1);
+      float* const lg = overlap ? b.d_layer_grads + (size_t)l * layer_floats * b.layer_grad_rows : nullptr;
+      float* const dth = overlap ? lg : dth0;
       // 3. transform backward
       if (d.kind == NF_KIND_AFFINE_MASKED) {
         hipLaunchKernelGGL(affine_masked_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, vc, gc, th, dth, n, D,
@@ -714,13 +738,19 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
         continue;
       }
       const float* gcur = dth;
+      const float* gkept[NF_MAX_HIDDEN + 1] = {nullptr};   // overlap: the gradient that entered Linear j
       for (int j = nlin - 1; j >= 0; --j) {
         const Linear& L = Ls[j];
         const float* ain = j == 0 ? vc : recorded(j - 1);
         const int lain = j == 0 ? D : Ls[j - 1].N;
-        NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
-                             b.partial_floats, stream));
+        if (overlap) gkept[j] = gcur;
+        else
+          NF_TRY(accumulate_tn(ain, lain, gcur, L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
+                               b.partial_floats, stream));
         float* gprev = (gcur == ga) ? gb : ga;
+        // overlap: the hidden gradients of this layer stay (slot j - 1 behind d theta); the last one, d x, is consumed
+        // by add_kernel right away and may share
+        if (overlap && j > 0) gprev = lg + (size_t)b.layer_grad_rows * ((size_t)param_width + (size_t)(j - 1) * gwidth);
         // j > 0: times act'(a_{j-1}) in the GEMM's epilogue (codes 3 / 4, masked by the sign of `ain`)
         NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gprev, L.K, (int)n, L.K,
                            L.N, j > 0 ? act + 2 : 0, stream, j > 0 ? ain : nullptr));
@@ -730,8 +760,23 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
         }
         gcur = gprev;
       }
+      if (overlap) {
+        NF_HIP(hipEventRecord(b.ev[l], stream));
+        NF_HIP(hipStreamWaitEvent(b.side, b.ev[l], 0));
+        for (int j = nlin - 1; j >= 0; --j) {
+          const Linear& L = Ls[j];
+          const float* ain = j == 0 ? vc : recorded(j - 1);
+          const int lain = j == 0 ? D : Ls[j - 1].N;
+          NF_TRY(accumulate_tn(ain, lain, gkept[j], L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
+                               b.partial_floats, b.side));
+        }
+      }
       NF_HIP(hipGetLastError());
     }
+  }
+  if (overlap) {   // the gradient is whole once the side stream is through
+    NF_HIP(hipEventRecord(b.ev[d.num_layers], b.side));
+    NF_HIP(hipStreamWaitEvent(stream, b.ev[d.num_layers], 0));
   }
   if (grad_canon)
     hipLaunchKernelGGL(scatter_grad_kernel, dim3(grid_for((long long)b.n_weights, 2048)), dim3(256), 0, stream, b.d_grad,

@@ -51,6 +51,7 @@ struct Switches {
   int split2d_samples = 0, split2d_grid = 0;  // 0 = unset
   int splitk_s = 0;                           // NF_SPLITK_S (development): number of k splits of the few-tile GEMMs
   bool no_tn_few_rows = false;                // NF_NO_TN_FEW_ROWS: 32 x 32 tiles for every weight gradient
+  bool no_bwd_overlap = false;                // NF_NO_BWD_OVERLAP: weight gradients inside the chain, one stream
   bool no_small_m_rqs = false;                // NF_NO_SMALL_M_RQS: split-K slabs + rqs_rows_kernel at small batches
   int small_m_nt = 0;                         // NF_SMALL_M_NT = 1 | 2 | 4: column blocks per workgroup of gemm_small_m_kernel (any N); 8: any N, automatic form
   long long inline_tail_rows = 0;             // NF_INLINE_TAIL_LG (clamped to [0, 40]); 0 = unset
@@ -339,6 +340,12 @@ struct Plan {
     long long tape_rows = 0;
     float* d_acts = nullptr;         // every Linear's output of that walk: [tape_rows][N] at act_off[layer*nlin+j]
     std::vector<size_t> act_off;
+    // small batches: the weight-gradient products leave the chain of data gradients and run beside it on a second
+    // stream (Plan::backward); every layer then keeps its own gradient buffers so that nothing is overwritten under them
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;      // one per layer + the side stream's last
+    float* d_layer_grads = nullptr;  // [num_layers][rows][param_width + num_hidden * gwidth]
+    long long layer_grad_rows = 0;
   } bwd;
   // SURVEY's K5 (spline layers whose last Linear is wide enough for the MFMA GEMM): weights of that Linear
   // re-laid so that a 128-column block holds whole transformed dims; the spline runs in the GEMM epilogue
