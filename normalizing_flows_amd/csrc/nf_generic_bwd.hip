@@ -393,11 +393,13 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
 // rows).  tn_partial_kernel's 32 x 32 tiles read 32 KB of operands per 4 KB of result with one 4-byte-per-lane load per
 // MFMA operand: 164 MB of L2 -> CU traffic and 2,600 wave-loads per CU, 37 us per launch against 8 us of MFMA time, a
 // quarter of the training step at batch 128 (EXPERIMENTS 3.8).  Here: one workgroup = 64 x 128 of the result, eight
-// waves with one 32 x 32 tile each; 64 rows of both operands at a time are staged through LDS with 16-byte loads (48 KB:
-// three workgroups per CU, so one's staging runs under another's MFMAs), MFMA operands are 4-byte LDS reads (lane =
-// column: conflict-free).  66 MB of L2 -> CU traffic, a quarter of the vector-memory instructions.  Every result
-// element belongs to one lane: added straight into the gradient.
-constexpr int kTnChunk = 64;
+// waves with one 32 x 32 tile each; 32 rows of both operands at a time are staged through LDS with 16-byte loads, MFMA
+// operands are 4-byte LDS reads (lane = column: conflict-free).  66 MB of L2 -> CU traffic, a quarter of the
+// vector-memory instructions.  Every result element belongs to one lane: added straight into the gradient.
+// 24 KB of LDS, so that three of these workgroups fit on a CU BESIDE one of gemm_splitk_kernel's (80 KB): Plan::backward
+// runs the two on different streams, and with 64-row stages (48 KB) the data-gradient GEMM waited for LDS and took 50 us
+// instead of 20 (training step 1.757 ms against 1.663).
+constexpr int kTnChunk = 32;
 __global__ __launch_bounds__(512) void tn_few_rows_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, int rows, int K, int N,
                                                           int tiles_n, float* __restrict__ grad_w,
