@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m16_kernel(const
                                                                           const float* __restrict__ W,
                                                                           const float* __restrict__ bias,
                                                                           float* __restrict__ Cm, int ldc, int M, int N,
-                                                                          int K, int act, const float* __restrict__ aux) {
+                                                                          int K, int act, const float* __restrict__ aux,
+                                                                          float* __restrict__ a_copy) {
   __shared__ float red[kSmallMWaves][4][64];   // every wave's raw 16 x 16 tile (16 KB)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m16_kernel(const
   const int col = min(n0 + i, N - 1);
   const float* ap = A + (size_t)row * lda;
   const float* wp = W + col;
+  const bool copy_a = a_copy != nullptr && blockIdx.x == 0 && m0 + i < M;
 
   f32x4v acc = {0.f, 0.f, 0.f, 0.f};
   float4 a[2][kSmallM16Groups];
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m16_kernel(const
       const bool live = g < g_end && k < K;
       const int kc = min(k, K - 4);
       float4 v = *reinterpret_cast<const float4*>(ap + kc);
+      // training: the first column block also leaves A in the tape (every element of its rows passes through exactly
+      // one live lane) -- the layer's input, without a copy launch
+      if (copy_a && live) *reinterpret_cast<float4*>(a_copy + (size_t)row * lda + kc) = v;
       if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
       a[buf][c] = v;
 #pragma unroll
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(kSmallMWaves * 64) void gemm_small_m16_kernel(const
       v += bias[ocol];
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = v >= 0.f ? v : 0.01f * v;
+      else if (act == 5) v += Cm[(size_t)orow * ldc + ocol];   // C += A W (the backward walk's d x)
       else if (act >= 3) v = aux[(size_t)orow * ldc + ocol] > 0.f ? v : (act == 4 ? 0.01f * v : 0.f);
       Cm[(size_t)orow * ldc + ocol] = v;
     }
@@ -219,15 +225,22 @@ bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K) {
          (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
+// The 16 x 16 form (one resident round of small tiles) is the one that can also copy A (a_copy) and add into C (act 5).
+bool gemm_small_m16_applicable(const float* A, int lda, int M, int N, int K) {
+  return gemm_small_m_applicable(A, lda, M, N, K) && (long long)((N + 15) / 16) * ((M + 15) / 16) <= 512 &&
+         (switches().small_m_nt == 0 || switches().small_m_nt == 8);
+}
+
 int launch_gemm_small_m(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N,
-                        int K, int act, hipStream_t stream, const float* aux) {
+                        int K, int act, hipStream_t stream, const float* aux, float* a_copy) {
   // small enough for one resident round of 16 x 16 tiles: all 256 CUs take part (NF_SMALL_M_NT set: the 32 x 32 forms)
-  if ((long long)((N + 15) / 16) * ((M + 15) / 16) <= 512 && (switches().small_m_nt == 0 || switches().small_m_nt == 8)) {
+  if (gemm_small_m16_applicable(A, lda, M, N, K)) {
     hipLaunchKernelGGL(gemm_small_m16_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(kSmallMWaves * 64), 0, stream, A, lda, W,
-                       bias, Cm, ldc, M, N, K, act, aux);
+                       bias, Cm, ldc, M, N, K, act, aux, a_copy);
     NF_HIP(hipGetLastError());
     return NF_OK;
   }
+  if (a_copy != nullptr || act == 5) { set_error("this Linear's shape has no copying / accumulating form"); return NF_ERR_UNSUPPORTED; }
   const int gy = (M + 31) / 32;
   // wider column blocks once the grid fills the chip anyway: A's rows are then fetched by fewer workgroups
   int NT = 1;

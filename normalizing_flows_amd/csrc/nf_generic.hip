@@ -491,10 +491,11 @@ static float* splitk_scratch(hipStream_t stream, size_t floats, int use = 0) {
 // act: 0 none, 1 relu, 2 leaky_relu; 3 / 4: the backward forms -- the result is multiplied by
 // relu' / leaky_relu' of `aux` (an activation OUTPUT of the same shape and leading dimension as C)
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc,
-                       int M, int N, int K, int act, hipStream_t stream, const float* aux) {
+                       int M, int N, int K, int act, hipStream_t stream, const float* aux, float* a_copy) {
   // few rows (the reference's batch of 128): the whole product in one launch of sixteen-wave workgroups
   if (gemm_small_m_applicable(A, lda, M, N, K) && !switches().gemm_simple)
-    return launch_gemm_small_m(A, lda, W, bias, Cm, ldc, M, N, K, act, stream, aux);
+    return launch_gemm_small_m(A, lda, W, bias, Cm, ldc, M, N, K, act, stream, aux, a_copy);
+  if (a_copy != nullptr || act == 5) { set_error("this Linear's shape has no copying / accumulating form"); return NF_ERR_UNSUPPORTED; }
   const bool aligned = (lda & 3) == 0 && (N & 3) == 0 && (K & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
   if (aligned && N >= 128 && K >= 32 && !switches().gemm_simple) {
@@ -1574,7 +1575,10 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
       // kernel writes it while it loads its input tile
       float* tape = record_tape ? bwd.d_tape + ((size_t)l * bwd.tape_rows + r0) * D : nullptr;
       const bool tape_in_kernel = narrow && a == yc && Ls[0].K == D;
-      if (record_tape && !tape_in_kernel)
+      // small batches: the first Linear's one-launch kernel leaves its input in the tape as it reads it
+      const bool tape_by_l1 = record_tape && !narrow && nlin > 1 && a == yc && Ls[0].K == D && !(x3 && d_wx3) &&
+                              !switches().gemm_simple && gemm_small_m16_applicable(yc, D, (int)n, Ls[0].N, Ls[0].K);
+      if (record_tape && !tape_in_kernel && !tape_by_l1)
         NF_HIP(hipMemcpyAsync(tape, yc, sizeof(float) * n * D, hipMemcpyDeviceToDevice, stream));
       if (narrow) {
         // narrow conditioner: one launch, activations stay in LDS (recorded only for the training walk)
@@ -1667,7 +1671,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
           NF_TRY(launch_gemm(xc, kpad, d_w1c + w1c_off[l], d_weights + L.b_off, dst, L.N, (int)n, L.N, kpad, act, stream));
         } else
           NF_TRY(launch_gemm(a, lda, d_weights + L.w_off, d_weights + L.b_off, dst, L.N, (int)n, L.N, L.K,
-                             j == nlin - 1 ? 0 : act, stream));
+                             j == nlin - 1 ? 0 : act, stream, nullptr, (j == 0 && tape_by_l1) ? tape : nullptr));
         a = dst;
         lda = L.N;
       }

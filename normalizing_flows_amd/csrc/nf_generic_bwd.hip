@@ -753,6 +753,12 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
         // overlap: the hidden gradients of this layer stay (slot j - 1 behind d theta); the last one, d x, is consumed
         // by add_kernel right away and may share
         if (overlap && j > 0) gprev = lg + (size_t)b.layer_grad_rows * ((size_t)param_width + (size_t)(j - 1) * gwidth);
+        if (j == 0 && !switches().gemm_simple && gemm_small_m16_applicable(gcur, L.N, (int)n, L.K, L.N)) {
+          // small batches: d x += g W_1^T in the GEMM's own epilogue (no separate add)
+          NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gc, D, (int)n, L.K, L.N, 5, stream));
+          gcur = gprev;
+          continue;
+        }
         // j > 0: times act'(a_{j-1}) in the GEMM's epilogue (codes 3 / 4, masked by the sign of `ain`)
         NF_TRY(launch_gemm(gcur, L.N, b.d_wT + b.wT_off[(size_t)l * nlin + j], b.d_zero, gprev, L.K, (int)n, L.K,
                            L.N, j > 0 ? act + 2 : 0, stream, j > 0 ? ain : nullptr));

@@ -286,12 +286,14 @@ struct RqsConst {
   float range_min, range_max, min_bin, min_slope, slope_offset;
 };
 RqsConst make_rqs_const(const nf_flow_desc& d);
+// a_copy / act 5 (C += A W): only where gemm_small_m16_applicable() says so
 int launch_gemm(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K,
-                int act, hipStream_t stream, const float* aux = nullptr);
+                int act, hipStream_t stream, const float* aux = nullptr, float* a_copy = nullptr);
 // nf_gemm_small_m.hip: one Linear at M <= 256 rows in one launch (no split-K slabs, no reduction launch)
 bool gemm_small_m_applicable(const float* A, int lda, int M, int N, int K);
+bool gemm_small_m16_applicable(const float* A, int lda, int M, int N, int K);
 int launch_gemm_small_m(const float* A, int lda, const float* W, const float* bias, float* Cm, int ldc, int M, int N,
-                        int K, int act, hipStream_t stream, const float* aux);
+                        int K, int act, hipStream_t stream, const float* aux, float* a_copy = nullptr);
 // nf_small_m_rqs.hip: a masked spline layer's last Linear + the spline at M <= 256 rows in one launch; the log-dets
 // arrive as [column group][row] partials (small_m_rqs_groups() of them per layer; 0: not a shape for that kernel)
 int small_m_rqs_groups(const float* A, int lda, int M, int N, int Kdim, int Dt, int bins);
