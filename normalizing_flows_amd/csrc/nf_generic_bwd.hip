@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ B, int ldb,
                                                          float* __restrict__ partial, long long rows,
                                                          long long chunk_rows, int K, int N, int tiles_n,
-                                                         float* __restrict__ grad_w, float* __restrict__ grad_b) {
+                                                         float* __restrict__ grad_w, float* __restrict__ grad_b,
+                                                         int overwrite) {
   __shared__ float red[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
     if (kk <= K && nn < N) {
       const float t = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
       if (grad_w == nullptr) out[(size_t)kk * N + nn] = t;
-      else if (kk < K) grad_w[(size_t)kk * N + nn] += t;
-      else grad_b[nn] += t;
+      else if (kk < K) grad_w[(size_t)kk * N + nn] = overwrite ? t : grad_w[(size_t)kk * N + nn] + t;
+      else grad_b[nn] = overwrite ? t : grad_b[nn] + t;
     }
   }
 }
@@ -403,7 +404,7 @@ constexpr int kTnChunk = 32;
 __global__ __launch_bounds__(512) void tn_few_rows_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, int rows, int K, int N,
                                                           int tiles_n, float* __restrict__ grad_w,
-                                                          float* __restrict__ grad_b) {
+                                                          float* __restrict__ grad_b, int overwrite) {
   __shared__ __attribute__((aligned(16))) float As[kTnChunk][64];
   __shared__ __attribute__((aligned(16))) float Bs[kTnChunk][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,8 +459,8 @@ __global__ __launch_bounds__(512) void tn_few_rows_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = kb + kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (kk < K) grad_w[(size_t)kk * N + nn] += acc[r];
-      else if (kk == K) grad_b[nn] += acc[r];
+      if (kk < K) grad_w[(size_t)kk * N + nn] = overwrite ? acc[r] : grad_w[(size_t)kk * N + nn] + acc[r];
+      else if (kk == K) grad_b[nn] = overwrite ? acc[r] : grad_b[nn] + acc[r];
     }
   }
 }
@@ -489,9 +490,12 @@ static int grid_for(long long total, int cap = 8192) {
   return (int)std::max<long long>(1, std::min<long long>(cap, (total + 255) / 256));
 }
 
-// grad_w[K*N] += A^T B, grad_b[N] += column sums of B
+// grad_w[K*N] += A^T B, grad_b[N] += column sums of B.  overwrite (only honoured on the one-chunk routes, which the
+// caller has checked with tn_one_chunk()): = instead of +=, for a gradient buffer that was not zeroed.
+static bool tn_one_chunk(long long rows) { return rows < 512; }   // below: want <= rows / 256 <= 1
 static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long long rows, int K, int N,
-                         float* grad_w, float* grad_b, float* partials, size_t partial_floats, hipStream_t stream) {
+                         float* grad_w, float* grad_b, float* partials, size_t partial_floats, hipStream_t stream,
+                         bool overwrite = false) {
   const size_t count = (size_t)(K + 1) * N;
   const int tiles_k = (K + 1 + 31) / 32, tiles_n = (N + 31) / 32;
   // enough row chunks to fill the chip even when the result has few tiles (64 x 64: four)
@@ -507,13 +511,14 @@ static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long 
                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
   if (nchunks == 1 && rows <= 256 && quads && (long long)wide_k * wide_n >= 256 && !switches().no_tn_few_rows) {
     hipLaunchKernelGGL(tn_few_rows_kernel, dim3(wide_k * wide_n), dim3(512), 0, stream, A, lda, B, ldb, (int)rows, K, N,
-                       wide_n, grad_w, grad_b);
+                       wide_n, grad_w, grad_b, overwrite ? 1 : 0);
   } else if (nchunks == 1) {
     hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, 1), dim3(256), 0, stream, A, lda, B, ldb, partials,
-                       rows, chunk_rows, K, N, tiles_n, grad_w, grad_b);
+                       rows, chunk_rows, K, N, tiles_n, grad_w, grad_b, overwrite ? 1 : 0);
   } else {
+    if (overwrite) { set_error("weight gradient: overwrite asked for on the chunked route"); return NF_ERR_STATE; }
     hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, nchunks), dim3(256), 0, stream, A, lda, B, ldb,
-                       partials, rows, chunk_rows, K, N, tiles_n, (float*)nullptr, (float*)nullptr);
+                       partials, rows, chunk_rows, K, N, tiles_n, (float*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, partials, nchunks,
                        (size_t)K * N, (size_t)N, grad_w, grad_b);
   }
@@ -539,6 +544,7 @@ int Plan::prepare_backward() {
   b.ready = false;
   b.n_weights = host_weights.size();
   NF_HIP(hipMalloc(&b.d_grad, b.n_weights * sizeof(float)));
+  NF_HIP(hipMemset(b.d_grad, 0, b.n_weights * sizeof(float)));   // (a walk that overwrites skips the alignment gaps)
   NF_HIP(hipMalloc(&b.d_canon_index, b.n_weights * sizeof(int)));
   NF_HIP(hipMemcpy(b.d_canon_index, canon_index.data(), b.n_weights * sizeof(int), hipMemcpyHostToDevice));
   size_t wt = 0, biggest = 0;
@@ -689,7 +695,10 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
       b.layer_grad_rows = rows;
     }
   }
-  NF_HIP(hipMemsetAsync(b.d_grad, 0, b.n_weights * sizeof(float), stream));
+  // one row chunk and every product on a one-chunk route: each gradient entry is written exactly once, so the
+  // products store instead of adding and the 186 MB memset goes (the alignment gaps were zeroed when the buffer was made)
+  const bool fresh = overlap && tn_one_chunk(rows);
+  if (!fresh) NF_HIP(hipMemsetAsync(b.d_grad, 0, b.n_weights * sizeof(float), stream));
   if (grad_canon) NF_HIP(hipMemsetAsync(grad_canon, 0, weight_count * sizeof(float), stream));
   hipLaunchKernelGGL(base_grad_kernel, dim3(grid_for(rows * D)), dim3(256), 0, stream, v, g, rows * D, d.base, inv_n);
 
@@ -776,7 +785,7 @@ int Plan::backward(const float* v, float* g, long long rows, long long rows_glob
           const float* ain = j == 0 ? vc : recorded(j - 1);
           const int lain = j == 0 ? D : Ls[j - 1].N;
           NF_TRY(accumulate_tn(ain, lain, gkept[j], L.N, n, L.K, L.N, b.d_grad + L.w_off, b.d_grad + L.b_off, b.d_partials,
-                               b.partial_floats, b.side));
+                               b.partial_floats, b.side, fresh));
         }
       }
       NF_HIP(hipGetLastError());

@@ -118,6 +118,28 @@ def test_mnist_shape_gradient(nfa, monkeypatch, rows):
     check_grads(f, spec, x, tol=5e-4)   # 392 transformed dims feed every conditioner weight
 
 
+def test_small_batch_gradient_leaves_nothing_behind(nfa):
+    """Below 512 rows the general backward walk does not zero its gradient buffer: every weight-gradient product stores
+    instead of adding (on a second stream, beside the data-gradient chain).  A second call on other rows must not see
+    the first one's gradient, a larger call (which zeroes and adds) in between neither."""
+    spec = O.make_rqs_spec(3, event_size=40, hidden=(96, 80), num_bins=6, range_min=-3.0, range_max=3.0, final_std=0.05)
+    rng = np.random.default_rng(3)
+    x1 = (rng.standard_normal((200, 40)) * 1.2).astype(np.float32)
+    x2 = (rng.standard_normal((77, 40)) * 1.2).astype(np.float32)
+    x3 = (rng.standard_normal((700, 40)) * 1.2).astype(np.float32)
+    f = rqs_flow(nfa, spec)
+    assert f.kernel_name == "generic_gemm"
+    f.nll_grad(x1)
+    _, g2 = f.nll_grad(x2)
+    _, g3 = f.nll_grad(x3)
+    _, g2_again = f.nll_grad(x2)
+    _, g2_fresh = rqs_flow(nfa, spec).nll_grad(x2)
+    _, g3_fresh = rqs_flow(nfa, spec).nll_grad(x3)
+    assert np.array_equal(_flat(g2), _flat(g2_fresh)) and np.array_equal(_flat(g2_again), _flat(g2_fresh))
+    assert np.array_equal(_flat(g3), _flat(g3_fresh))
+    check_grads(f, spec, x2, tol=5e-4)
+
+
 def test_spline_adam_steps_and_fused_kernel_follows(nfa):
     """Three `update` steps on the configs[2] flow against optax.adam restated in float64; afterwards
     the fused kernel (log_prob) and the general path (training) must agree on the new weights."""
