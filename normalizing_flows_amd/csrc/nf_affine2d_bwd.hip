@@ -643,12 +643,12 @@ int launch_gather(const float* partials, int nparts, int num_layers, int first_m
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                                    float b1, float b2, float eps, float c1, float c2,
-                                                   const int* __restrict__ skip, const int* __restrict__ live) {
+                                                   const int* __restrict__ skip, const unsigned* __restrict__ live) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n || (skip != nullptr && *skip != 0)) return;
   // plan layout (generic::Plan): entries without a canonical weight behind them (masked rows of the first Linear,
   // alignment gaps) hold zeros that the products rely on; their "gradient" is not one
-  if (live != nullptr && live[e] < 0) return;
+  if (live != nullptr && ((live[e >> 5] >> (e & 31)) & 1u) == 0) return;
   // optax.adam (src/real_nvp_toy_densities.py:162): m, v moments, bias-corrected by c1 = 1-b1^t, c2 = 1-b2^t
   const float ge = g[e];
   const float me = b1 * m[e] + (1.f - b1) * ge;
@@ -659,9 +659,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, size_t n, float lr,
-                                                  const int* __restrict__ skip, const int* __restrict__ live) {
+                                                  const int* __restrict__ skip, const unsigned* __restrict__ live) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < n && !(skip != nullptr && *skip != 0) && !(live != nullptr && live[e] < 0)) w[e] -= lr * g[e];  // src/real_nvp.py:298
+  if (e < n && !(skip != nullptr && *skip != 0) && !(live != nullptr && ((live[e >> 5] >> (e & 31)) & 1u) == 0)) w[e] -= lr * g[e];  // src/real_nvp.py:298
 }
 
 // *flag = 1 when any gradient entry is NaN or infinite (flag zeroed by the caller): the "skip_nonfinite_updates"
@@ -704,10 +704,10 @@ __global__ __launch_bounds__(256) void adam_dev_bias_kernel(float* __restrict__ 
                                                             float* __restrict__ m, float* __restrict__ v, size_t n,
                                                             float lr, float b1, float b2, float eps,
                                                             const float* __restrict__ bias,
-                                                            const int* __restrict__ skip, const int* __restrict__ live) {
+                                                            const int* __restrict__ skip, const unsigned* __restrict__ live) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n || *skip != 0) return;
-  if (live != nullptr && live[e] < 0) return;
+  if (live != nullptr && ((live[e >> 5] >> (e & 31)) & 1u) == 0) return;
   const float c1 = bias[0], c2 = bias[1];
   const float ge = g[e];
   const float me = b1 * m[e] + (1.f - b1) * ge;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void adam_dev_bias_kernel(float* __restrict__ 
 }
 
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                long long step, hipStream_t stream, const int* skip, float* dev_bias, const int* live) {
+                long long step, hipStream_t stream, const int* skip, float* dev_bias, const unsigned* live) {
   if (skip != nullptr && dev_bias != nullptr) {
     hipLaunchKernelGGL(adam_bias_kernel, dim3(1), dim3(1), 0, stream, dev_bias, skip, b1, b2);
     hipLaunchKernelGGL(adam_dev_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr,
@@ -733,7 +733,7 @@ int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr
   return NF_OK;
 }
 
-int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip, const int* live) {
+int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip, const unsigned* live) {
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, n, lr, skip, live);
   NF_HIP(hipGetLastError());
   return NF_OK;

@@ -1345,7 +1345,7 @@ void Plan::release() {
   w1c = false;
   if (d_wsmr) { hipFree(d_wsmr); d_wsmr = nullptr; }
   hipFree(bwd.d_grad); hipFree(bwd.d_wT); hipFree(bwd.d_canon_index); hipFree(bwd.d_zero); hipFree(bwd.d_partials);
-  hipFree(bwd.d_small_partials);
+  hipFree(bwd.d_small_partials); hipFree(bwd.d_live_bits);
   hipFree(bwd.d_scratch); hipFree(bwd.d_tape); hipFree(bwd.d_acts); hipFree(bwd.d_jobs);
   if (bwd.side) { hipStreamSynchronize(bwd.side); hipStreamDestroy(bwd.side); }
   for (hipEvent_t e : bwd.ev) hipEventDestroy(e);

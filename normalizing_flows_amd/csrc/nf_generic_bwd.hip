@@ -547,6 +547,15 @@ int Plan::prepare_backward() {
   NF_HIP(hipMemset(b.d_grad, 0, b.n_weights * sizeof(float)));   // (a walk that overwrites skips the alignment gaps)
   NF_HIP(hipMalloc(&b.d_canon_index, b.n_weights * sizeof(int)));
   NF_HIP(hipMemcpy(b.d_canon_index, canon_index.data(), b.n_weights * sizeof(int), hipMemcpyHostToDevice));
+  {
+    std::vector<unsigned> bits((b.n_weights + 31) / 32, 0u);
+    for (size_t e = 0; e < b.n_weights; ++e)
+      if (canon_index[e] >= 0) bits[e >> 5] |= 1u << (e & 31);
+    hipFree(b.d_live_bits);
+    b.d_live_bits = nullptr;
+    NF_HIP(hipMalloc(&b.d_live_bits, bits.size() * sizeof(unsigned)));
+    NF_HIP(hipMemcpy(b.d_live_bits, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  }
   size_t wt = 0, biggest = 0;
   int widest = desc.event_dim;
   b.wT_off.clear();

@@ -164,9 +164,9 @@ int launch_gather(const float* partials, int nparts, int num_layers, int first_m
 int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 long long step, hipStream_t stream, const int* skip = nullptr,  // *skip != 0: leave everything as it is
                 float* dev_bias = nullptr,  // [3] with skip: device-side step count and bias corrections (applied steps only)
-                const int* live = nullptr);  // [n] or null: entries with live[e] < 0 are left alone (plan layout)
+                const unsigned* live = nullptr);  // one bit per entry or null: entries whose bit is 0 are left alone (plan layout)
 int launch_sgd(float* w, const float* g, size_t n, float lr, hipStream_t stream, const int* skip = nullptr,
-               const int* live = nullptr);
+               const unsigned* live = nullptr);
 int launch_nonfinite_flag(const float* g, size_t n, int* flag, hipStream_t stream);  // *flag = any NaN / inf in g
 int launch_repack(const float* canon, const int* src, const signed char* shift, float* img, size_t n,
                   hipStream_t stream);
@@ -330,6 +330,7 @@ struct Plan {
     float* d_wT = nullptr;           // every Linear's W transposed, [N][K], at wT_off
     std::vector<size_t> wT_off;
     int* d_canon_index = nullptr;
+    unsigned* d_live_bits = nullptr;  // bit e: d_canon_index[e] >= 0 (what the optimiser reads: 1/32 of the index map's bytes)
     void* d_jobs = nullptr;          // per-Linear table of the one-launch transpose
     int transpose_blocks = 1;
     float* d_zero = nullptr;         // zero bias for the data-gradient GEMMs

@@ -355,8 +355,8 @@ int nf_train_step(nf_flow* f, const float* x, int64_t rows_local, int64_t rows_g
   float* canon = f->path == PATH_SPLIT2D_SMALL ? f->d_wimg : t.d_canon;
   float* grad = t.d_grad;
   size_t count = f->weight_count;
-  const int* live = nullptr;
-  if (t.plan_layout) { canon = f->plan.d_weights; grad = f->plan.bwd.d_grad; count = t.opt_count; live = f->plan.bwd.d_canon_index; }
+  const unsigned* live = nullptr;
+  if (t.plan_layout) { canon = f->plan.d_weights; grad = f->plan.bwd.d_grad; count = t.opt_count; live = f->plan.bwd.d_live_bits; }
   const int* skip = nullptr;
   if (f->skip_nonfinite) {
     if (!f->d_skip_flag) NF_HIP(hipMalloc(&f->d_skip_flag, sizeof(int)));
