@@ -52,6 +52,9 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #ifndef NF_SMR_LOOP
 #define NF_SMR_LOOP 0
 #endif
+#ifndef NF_SMR_NT
+#define NF_SMR_NT 0   // 1: non-temporal loads of W (26.2 us per launch against 24.4: the four row blocks share W through L2)
+#endif
 // -DNF_SMR_CLOCKS (profiles/microbench/small_m_rqs_clocks.hip): theta_out is a debug buffer, every wave leaves the shader
 // clock at six program points and the 100 MHz wall clock at entry and exit
 #ifdef NF_SMR_CLOCKS
@@ -144,7 +147,15 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
     const float4* wg = wl + __builtin_amdgcn_readfirstlane(g * (CT * 64));
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
+#if NF_SMR_NT
+      {
+        typedef float f32x4nt __attribute__((ext_vector_type(4)));
+        const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(wg + ct * 64));
+        b[buf][ct] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+#else
       b[buf][ct] = wg[ct * 64];
+#endif
       if (NF_SMR_SKIP & 2) b[buf][ct] = make_float4((float)g, 1.f, 2.f, (float)ct);
     }
   };
