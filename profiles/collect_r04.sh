@@ -33,6 +33,9 @@ for what in ${@:-bench c d a}; do
     # training steps at 2^20 rows: the fused affine step, the spline flow's general step
     train) NF_TRAIN_LG=20 collect gpurun_out/prof_r04_train r04/train_b_2p20 profiles/bench_configs.py train ;;
     trainc) NF_TRAINC_LG=20 collect gpurun_out/prof_r04_trainc r04/train_c_2p20 profiles/bench_configs.py trainc ;;
+    # the reference's own batch (128 rows of the 784-D flow): log_prob call and training step
+    mnist128) NF_MNIST_ROWS=128 collect gpurun_out/prof_r04_mnist128 r04/mnist_b128_logprob profiles/mnist_small_batch.py ;;
+    mnist128t) collect gpurun_out/prof_r04_mnist128t r04/train_mnist_b128 profiles/mnist_train_step.py ;;
   esac
 done
 # the box keeps nothing: the summaries travel back under gpurun_out/ and are copied into profiles/r04/ from there
