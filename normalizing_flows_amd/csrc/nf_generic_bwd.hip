@@ -403,13 +403,21 @@ __global__ __launch_bounds__(256) void tn_partial_kernel(const float* __restrict
 constexpr int kTnChunk = 32;
 __global__ __launch_bounds__(512) void tn_few_rows_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, int rows, int K, int N,
-                                                          int tiles_n, float* __restrict__ grad_w,
+                                                          int tiles_k, int tiles_n, float* __restrict__ grad_w,
                                                           float* __restrict__ grad_b, int overwrite) {
   __shared__ __attribute__((aligned(16))) float As[kTnChunk][64];
   __shared__ __attribute__((aligned(16))) float Bs[kTnChunk][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int kb = (blockIdx.x / tiles_n) * 64, nb = (blockIdx.x % tiles_n) * 128;
+  // Workgroup -> block, XCD-aware: workgroups are dealt to the eight XCDs round-robin (blockIdx.x % 8), and the
+  // tiles_k workgroups that share a 128-column block of B (64 KB of d theta per 64 rows) should find it in ONE L2:
+  // on XCD x, slot s = blockIdx.x / 8 walks column block 8 (s / tiles_k) + x with the k block s % tiles_k fastest.
+  // (Dealt out k-major, every column block was fetched from HBM by all nine k blocks: 62 MB per launch, rocprofv3
+  // FETCH_SIZE, against 25 MB of operands + result.)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nblock = 8 * (slot / tiles_k) + xcd;
+  if (nblock >= tiles_n) return;   // (the grid is rounded up to whole rounds of eight column blocks; no barrier reached yet)
+  const int kb = (slot % tiles_k) * 64, nb = nblock * 128;
   const int kt = 32 * (wave & 1), nt = 32 * (wave >> 1);
   f32x16 acc;
 #pragma unroll
@@ -510,8 +518,8 @@ static int accumulate_tn(const float* A, int lda, const float* B, int ldb, long 
   const bool quads = (lda & 3) == 0 && (ldb & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
   if (nchunks == 1 && rows <= 256 && quads && (long long)wide_k * wide_n >= 256 && !switches().no_tn_few_rows) {
-    hipLaunchKernelGGL(tn_few_rows_kernel, dim3(wide_k * wide_n), dim3(512), 0, stream, A, lda, B, ldb, (int)rows, K, N,
-                       wide_n, grad_w, grad_b, overwrite ? 1 : 0);
+    hipLaunchKernelGGL(tn_few_rows_kernel, dim3(8 * wide_k * ((wide_n + 7) / 8)), dim3(512), 0, stream, A, lda, B, ldb,
+                       (int)rows, K, N, wide_k, wide_n, grad_w, grad_b, overwrite ? 1 : 0);
   } else if (nchunks == 1) {
     hipLaunchKernelGGL(tn_partial_kernel, dim3(tiles_k * tiles_n, 1), dim3(256), 0, stream, A, lda, B, ldb, partials,
                        rows, chunk_rows, K, N, tiles_n, grad_w, grad_b, overwrite ? 1 : 0);
