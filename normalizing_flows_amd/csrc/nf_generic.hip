@@ -464,6 +464,58 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   }
 }
 
+// Many slabs over a small result (the backward walk's data gradient through a wide last Linear: 64 slabs of [128, 512]):
+// one thread per element walks S dependent-latency rounds (11.5 us for 16.8 MB).  Here sixteen waves share an element's
+// slabs -- wave w adds slabs [w c, (w + 1) c) of 64 float4 elements, all c loads in flight -- and the sixteen sums are
+// added in wave order (fixed: run-to-run identical; not the order of the kernel above, which keeps the small-S cases
+// whose order the spline kernel's slab sum mirrors).
+__global__ __launch_bounds__(1024) void gemm_splitk_reduce_wide_kernel(const float* __restrict__ partial, int S,
+                                                                       const float* __restrict__ bias,
+                                                                       float* __restrict__ Cm, int ldc, int M, int N,
+                                                                       int act, const float* __restrict__ aux) {
+  __shared__ float4 part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t total4 = (size_t)M * N / 4;
+  const size_t q = (size_t)blockIdx.x * 64 + lane;
+  const int c = (S + 15) / 16;
+  const int s0 = wave * c, s1 = min(S, s0 + c);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < total4) {
+    const float4* p4 = reinterpret_cast<const float4*>(partial) + q;
+    int sidx = s0;
+    for (; sidx + 4 <= s1; sidx += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = p4[(size_t)(sidx + u) * total4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    for (; sidx < s1; ++sidx) {
+      const float4 t = p4[(size_t)sidx * total4];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+  }
+  part[wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && q < total4) {
+    float4 r = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { const float4 t = part[w][lane]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    const size_t e = q * 4;
+    const int row = (int)(e / N), col = (int)(e - (size_t)row * N);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+    float o[4] = {r.x + b4.x, r.y + b4.y, r.z + b4.z, r.w + b4.w};
+    if (act == 1) { for (int u = 0; u < 4; ++u) o[u] = fmaxf(o[u], 0.f); }
+    else if (act == 2) { for (int u = 0; u < 4; ++u) o[u] = o[u] >= 0.f ? o[u] : 0.01f * o[u]; }
+    else if (act >= 3) {
+      const float4 a4 = *reinterpret_cast<const float4*>(aux + (size_t)row * ldc + col);
+      const float m[4] = {a4.x, a4.y, a4.z, a4.w};
+      for (int u = 0; u < 4; ++u) o[u] = m[u] > 0.f ? o[u] : (act == 4 ? 0.01f * o[u] : 0.f);
+    }
+    *reinterpret_cast<float4*>(Cm + (size_t)row * ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // grow-only scratch for the split-K slabs, one per (host thread, stream): handles are driven from one thread each,
 // and two handles of one thread run on different streams
 // (use 0: the slabs; use 1: the log-det partials of nf_small_m_rqs.hip, which live across a walk's layers)
@@ -515,6 +567,13 @@ int launch_gemm(const float* A, int lda, const float* W, const float* bias, floa
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * S), dim3(256), kFastLdsFloats * sizeof(float), stream, A, lda,
                          W, partial, M, N, K, Kc, gx, gy);
       const size_t total = (size_t)M * N;
+      const bool wide = S >= 16 && (N & 3) == 0 && (ldc & 3) == 0 && total <= ((size_t)1 << 22) && act != 5 &&
+                        ((reinterpret_cast<uintptr_t>(Cm) | reinterpret_cast<uintptr_t>(bias) |
+                          reinterpret_cast<uintptr_t>(aux)) & 15) == 0;
+      if (wide)
+        hipLaunchKernelGGL(gemm_splitk_reduce_wide_kernel, dim3((unsigned)((total / 4 + 63) / 64)), dim3(1024), 0, stream,
+                           partial, S, bias, Cm, ldc, M, N, act, aux);
+      else
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(2048, (total + 255) / 256)), dim3(256),
                          0, stream, partial, S, bias, Cm, ldc, M, N, act, aux);
       NF_HIP(hipGetLastError());
