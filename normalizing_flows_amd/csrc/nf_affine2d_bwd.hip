@@ -658,6 +658,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   w[e] -= lr * (me / c1) / (sqrtf(ve / c2) + eps);
 }
 
+// four entries per thread (16-byte accesses; n % 4 == 0, bases 16-byte aligned: the plan layout)
+__global__ __launch_bounds__(256) void adam4_kernel(float4* __restrict__ w, const float4* __restrict__ g,
+                                                    float4* __restrict__ m, float4* __restrict__ v, size_t n4, float lr,
+                                                    float b1, float b2, float eps, float c1, float c2,
+                                                    const int* __restrict__ skip, const unsigned* __restrict__ live) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n4 || (skip != nullptr && *skip != 0)) return;
+  const unsigned bits = live != nullptr ? (live[q >> 3] >> ((q & 7) * 4)) & 0xFu : 0xFu;
+  if (bits == 0) return;
+  const float4 g4 = g[q];
+  float4 m4 = m[q], v4 = v[q], w4 = w[q];
+  const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+  float me[4] = {m4.x, m4.y, m4.z, m4.w}, ve[4] = {v4.x, v4.y, v4.z, v4.w}, we[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (bits & (1u << u)) {   // the same arithmetic as adam_kernel, entry by entry
+      me[u] = b1 * me[u] + (1.f - b1) * ge[u];
+      ve[u] = b2 * ve[u] + (1.f - b2) * ge[u] * ge[u];
+      we[u] -= lr * (me[u] / c1) / (sqrtf(ve[u] / c2) + eps);
+    }
+  m[q] = make_float4(me[0], me[1], me[2], me[3]);
+  v[q] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+  w[q] = make_float4(we[0], we[1], we[2], we[3]);
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, size_t n, float lr,
                                                   const int* __restrict__ skip, const unsigned* __restrict__ live) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -727,6 +752,14 @@ int launch_adam(float* w, const float* g, float* m, float* v, size_t n, float lr
     return NF_OK;
   }
   const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                        reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+    hipLaunchKernelGGL(adam4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<float4*>(w),
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4,
+                       lr, b1, b2, eps, c1, c2, skip, live);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+  }
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2,
                      eps, c1, c2, skip, live);
   NF_HIP(hipGetLastError());
