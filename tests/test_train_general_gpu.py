@@ -140,6 +140,29 @@ def test_small_batch_gradient_leaves_nothing_behind(nfa):
     check_grads(f, spec, x2, tol=5e-4)
 
 
+def test_two_stream_backward_is_the_one_stream_backward(nfa, monkeypatch):
+    """Below 512 rows the weight-gradient products run on a second stream beside the data-gradient chain and store
+    into a gradient buffer that is not zeroed.  Same kernels, same order of additions per entry: six optimiser steps
+    must leave bit-identical weights and losses with and without it (NF_NO_BWD_OVERLAP) -- any race between the two
+    streams would show here."""
+    from normalizing_flows_amd import training
+    spec = O.make_rqs_spec(3, event_size=300, hidden=(64, 96), num_bins=4, range_min=-3.0, range_max=3.0, final_std=0.05)
+    rng = np.random.default_rng(11)
+    batches = [(rng.standard_normal((rows, 300)) * 1.2).astype(np.float32) for rows in (128, 77, 200, 128, 33, 128)]
+
+    def run():
+        f = rqs_flow(nfa, spec)
+        opt = training.adam(1e-3)
+        losses = [f.train_step(x, opt) for x in batches]
+        return losses, _flat(f.get_weights())
+
+    l_two, w_two = run()
+    monkeypatch.setenv("NF_NO_BWD_OVERLAP", "1")
+    l_one, w_one = run()
+    assert l_two == l_one
+    assert np.array_equal(w_two, w_one)
+
+
 def test_spline_adam_steps_and_fused_kernel_follows(nfa):
     """Three `update` steps on the configs[2] flow against optax.adam restated in float64; afterwards
     the fused kernel (log_prob) and the general path (training) must agree on the new weights."""
