@@ -140,15 +140,18 @@ def test_small_batch_gradient_leaves_nothing_behind(nfa):
     check_grads(f, spec, x2, tol=5e-4)
 
 
-def test_two_stream_backward_is_the_one_stream_backward(nfa, monkeypatch):
+@pytest.mark.parametrize("D,hidden,K,L,sizes", [(300, (64, 96), 4, 3, (128, 77, 200, 128, 33, 128)),
+                                                 # the 784-D shape: the LDS-staged wide weight gradient, 64 split-K slabs
+                                                 (784, (512, 512, 512), 8, 2, (128, 64, 33))])
+def test_two_stream_backward_is_the_one_stream_backward(nfa, monkeypatch, D, hidden, K, L, sizes):
     """Below 512 rows the weight-gradient products run on a second stream beside the data-gradient chain and store
     into a gradient buffer that is not zeroed.  Same kernels, same order of additions per entry: six optimiser steps
     must leave bit-identical weights and losses with and without it (NF_NO_BWD_OVERLAP) -- any race between the two
     streams would show here."""
     from normalizing_flows_amd import training
-    spec = O.make_rqs_spec(3, event_size=300, hidden=(64, 96), num_bins=4, range_min=-3.0, range_max=3.0, final_std=0.05)
+    spec = O.make_rqs_spec(L, event_size=D, hidden=hidden, num_bins=K, range_min=-3.0, range_max=3.0, final_std=0.05)
     rng = np.random.default_rng(11)
-    batches = [(rng.standard_normal((rows, 300)) * 1.2).astype(np.float32) for rows in (128, 77, 200, 128, 33, 128)]
+    batches = [(rng.standard_normal((rows, D)) * 1.2).astype(np.float32) for rows in sizes]
 
     def run():
         f = rqs_flow(nfa, spec)
