@@ -1653,8 +1653,14 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         const Linear& L = linears[(size_t)l * nlin + j];
         // (a batch of one or two row blocks leaves the fused kernel ~80 workgroups that each walk the whole K; the
         // split-K GEMM + the transform kernel are quicker there: 45 -> 32 us per layer at the MNIST shape, batch 128)
-        const bool k5_small = (long long)(k5_npad / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
-                              !switches().no_splitk;
+        // (<= 256 rows of a wide flow: nf_small_m_rqs.hip's one-launch last Linear + spline -- 580 -> 480 us per
+        // 8-layer call at the MNIST shape and 192 / 256 rows, where this kernel's 158 workgroups took 50 + 5 us per layer)
+        const bool small_m_rqs_first =
+            j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3) && n <= 256 && L.K >= 8 * 32 &&
+            small_m_rqs_groups(a, lda, (int)n, L.N, L.K, par == 0 ? D / 2 : (D + 1) / 2, rc.K) > 0;
+        const bool k5_small = small_m_rqs_first ||
+                              ((long long)(k5_npad / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
+                               !switches().no_splitk);
         if (j == nlin - 1 && k5 && !k5_small && !record_tape && (lda & 3) == 0 &&
             (reinterpret_cast<uintptr_t>(a) & 15) == 0) {
           // K5: GEMM + spline in one kernel; theta stays in LDS

@@ -80,7 +80,7 @@ struct SrShape {
   static constexpr int CT = (COLS + 15) / 16;
   static constexpr int STRIDE = COLS | 1;             // odd row stride of the parameter tile in LDS
   static constexpr int RED_FLOATS = kSrWaves * CT * 256;
-  static constexpr int LDS_FLOATS = RED_FLOATS + 32 * STRIDE + 32 * DW;
+  static constexpr int lds_floats(int RT) { return RED_FLOATS + 16 * RT * STRIDE + 16 * RT * DW; }
 };
 
 #if NF_SMR_SKIP & 1
@@ -89,7 +89,8 @@ __device__ __forceinline__ f32x4s SMR_MFMA(float a, float b, f32x4s c, int, int,
 #define SMR_MFMA __builtin_amdgcn_mfma_f32_16x16x4f32
 #endif
 
-template <int K, int INV>
+// RT: 16-row tiles per workgroup; 2 is what runs (see launch_k for the measurement of 4)
+template <int K, int INV, int RT>
 __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const float* __restrict__ A, int lda,
                                                                           const float4* __restrict__ Wp,
                                                                           const float* __restrict__ bias,
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
   constexpr int CT = S::CT, P = S::P, DW = S::DW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                           // [wave][column tile][register][lane]
-  float* prm = sm + S::RED_FLOATS;           // [32 rows][STRIDE]
-  float* ldv = prm + 32 * S::STRIDE;         // [32 rows][DW]
+  constexpr int ROWS = 16 * RT;
+  float* prm = sm + S::RED_FLOATS;           // [ROWS][STRIDE]
+  float* ldv = prm + ROWS * S::STRIDE;       // [ROWS][DW]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,11 +112,11 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
   // workgroup -> (column group, row block), XCD-aware: workgroups are dealt to the eight XCDs round-robin, and the row
   // blocks that share a column group's W should meet in ONE L2 (23.7 MB of HBM traffic per launch at the MNIST shape
   // against 20.2 MB of re-laid W: rocprofv3 FETCH_SIZE) -- whatever CG is
-  const int RG = (M + 31) >> 5;
+  const int RG = (M + 16 * RT - 1) / (16 * RT);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int cg = 8 * (slot / RG) + xcd, rg = slot % RG;
   if (cg >= CG) return;   // (the grid is rounded up to whole rounds of eight column groups; no barrier reached yet)
-  const int m0 = rg * 32;
+  const int m0 = rg * (16 * RT);
   const int Dt = N / P;
   const int dt0 = cg * DW;
   const int ndim = min(DW, Dt - dt0);
@@ -129,27 +131,28 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
   const int g_end = min(groups, g_begin + per);
   // addresses as a wave-uniform base (the group's k row) + loop-invariant 32-bit byte offsets per lane: rows / columns
   // past the edge are clamped, their results never used
-  const unsigned a_off0 = (unsigned)(((size_t)min(m0 + i, M - 1) * lda + 4 * kq) * sizeof(float));
-  const unsigned a_off1 = (unsigned)(((size_t)min(m0 + 16 + i, M - 1) * lda + 4 * kq) * sizeof(float));
+  unsigned a_off[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) a_off[rt] = (unsigned)(((size_t)min(m0 + 16 * rt + i, M - 1) * lda + 4 * kq) * sizeof(float));
   // W comes re-laid in operand order (pack_kernel below): the workgroup's share is one contiguous block, a wave's group
   // of 16 k is CT consecutive kilobytes, a lane's four k of one column tile one 16-byte load
   const float4* wl = Wp + (size_t)cg * groups * (CT * 64) + lane;
 
-  f32x4s acc[2][CT];
+  f32x4s acc[RT][CT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4s{0.f, 0.f, 0.f, 0.f};
 
   SMR_STAMP(1);
-  float4 a[2][2];
+  float4 a[2][RT];
   float4 b[2][CT];
   // (readfirstlane on an index that is wave-uniform anyway: it keeps the compiler's loop strength reduction from
   // turning every load's address into its own 64-bit induction pointer in vector registers)
   auto fetch = [&](int buf, int g) {
     const char* ag = reinterpret_cast<const char*>(A + __builtin_amdgcn_readfirstlane(16 * g));
-    a[buf][0] = *reinterpret_cast<const float4*>(ag + a_off0);
-    a[buf][1] = *reinterpret_cast<const float4*>(ag + a_off1);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[buf][rt] = *reinterpret_cast<const float4*>(ag + a_off[rt]);
     const float4* wg = wl + __builtin_amdgcn_readfirstlane(g * (CT * 64));
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -166,26 +169,12 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
     }
   };
   auto multiply = [&](int buf) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      acc[0][ct] = SMR_MFMA(a[buf][0].x, b[buf][ct].x, acc[0][ct], 0, 0, 0);
-      acc[1][ct] = SMR_MFMA(a[buf][1].x, b[buf][ct].x, acc[1][ct], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      acc[0][ct] = SMR_MFMA(a[buf][0].y, b[buf][ct].y, acc[0][ct], 0, 0, 0);
-      acc[1][ct] = SMR_MFMA(a[buf][1].y, b[buf][ct].y, acc[1][ct], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      acc[0][ct] = SMR_MFMA(a[buf][0].z, b[buf][ct].z, acc[0][ct], 0, 0, 0);
-      acc[1][ct] = SMR_MFMA(a[buf][1].z, b[buf][ct].z, acc[1][ct], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      acc[0][ct] = SMR_MFMA(a[buf][0].w, b[buf][ct].w, acc[0][ct], 0, 0, 0);
-      acc[1][ct] = SMR_MFMA(a[buf][1].w, b[buf][ct].w, acc[1][ct], 0, 0, 0);
-    }
+#define SMR_K_STEP(c_)                                                                            \
+  _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                              \
+      acc[rt][ct] = SMR_MFMA(a[buf][rt].c_, b[buf][ct].c_, acc[rt][ct], 0, 0, 0);
+    SMR_K_STEP(x) SMR_K_STEP(y) SMR_K_STEP(z) SMR_K_STEP(w)
+#undef SMR_K_STEP
   };
   // The k loop: a group's loads, then its 88 MFMAs -- no overlap between them.  What bounds this phase is how many bytes a
   // CU can pull (a workgroup reads 358 KB of W and 64 KB of A; 13 us at ~40 GB/s per CU, between the L2-hit and the
@@ -249,7 +238,7 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
 
   // the eight waves' tiles -> one parameter tile, one row tile (16 rows) at a time
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     if (rt) __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -276,7 +265,7 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
 
   // the spline: one thread per (row, transformed dim)
   const int first_t = pass_parity == 0 ? 1 : 0;
-  for (int it = tid; it < 32 * DW; it += kSrWaves * 64) {
+  for (int it = tid; it < ROWS * DW; it += kSrWaves * 64) {
     const int rl = it / DW, dl = it % DW;
     float l = 0.f;
     if (dl < ndim && m0 + rl < M) {
@@ -290,7 +279,7 @@ __global__ __launch_bounds__(kSrWaves * 64) void linear_rqs_small_m_kernel(const
   }
   __syncthreads();
   SMR_STAMP(4);
-  if (tid < 32 && m0 + tid < M) {
+  if (tid < ROWS && m0 + tid < M) {
     float s = 0.f;
     for (int dl = 0; dl < ndim; ++dl) s += ldv[tid * DW + dl];
     ldpart[(size_t)cg * M + m0 + tid] = s;
@@ -389,28 +378,36 @@ int small_m_rqs_groups(const float* A, int lda, int M, int N, int Kdim, int Dt, 
     default: return 0;
   }
   // a handful of workgroups is no way to run a chip: narrow flows keep the split-K route
-  return cg * ((M + 31) / 32) >= 32 ? cg : 0;
+  return cg * ((M + 31) / 32) >= 32 ? cg : 0;   // (counted in 32-row blocks, whichever block form runs)
 }
 
-template <int K>
-static int launch_k(const float* A, int lda, const float* Wp, const float* bias, float* y, float* ldpart, float* theta_out,
-                    int M, int N, int Kdim, int D, int par, int inverse_op, const RqsConst& rc, hipStream_t stream) {
+template <int K, int RT>
+static int launch_krt(const float* A, int lda, const float* Wp, const float* bias, float* y, float* ldpart, float* theta_out,
+                      int M, int N, int Kdim, int D, int par, int inverse_op, const RqsConst& rc, hipStream_t stream) {
   using S = SrShape<K>;
   const int Dt = N / S::P;
   const int CG = column_groups<K>(Dt);
-  const dim3 grid(8 * ((CG + 7) / 8) * ((M + 31) / 32));
-  const size_t lds = sizeof(float) * S::LDS_FLOATS;
+  const dim3 grid(8 * ((CG + 7) / 8) * ((M + 16 * RT - 1) / (16 * RT)));
+  const size_t lds = sizeof(float) * S::lds_floats(RT);
   if (inverse_op) {
-    NF_DYN_LDS((int)lds, &linear_rqs_small_m_kernel<K, 1>);
-    hipLaunchKernelGGL((linear_rqs_small_m_kernel<K, 1>), grid, dim3(kSrWaves * 64), lds, stream, A, lda,
+    NF_DYN_LDS((int)lds, &linear_rqs_small_m_kernel<K, 1, RT>);
+    hipLaunchKernelGGL((linear_rqs_small_m_kernel<K, 1, RT>), grid, dim3(kSrWaves * 64), lds, stream, A, lda,
                        reinterpret_cast<const float4*>(Wp), bias, y, ldpart, theta_out, M, N, Kdim, D, par, CG, rc);
   } else {
-    NF_DYN_LDS((int)lds, &linear_rqs_small_m_kernel<K, 0>);
-    hipLaunchKernelGGL((linear_rqs_small_m_kernel<K, 0>), grid, dim3(kSrWaves * 64), lds, stream, A, lda,
+    NF_DYN_LDS((int)lds, &linear_rqs_small_m_kernel<K, 0, RT>);
+    hipLaunchKernelGGL((linear_rqs_small_m_kernel<K, 0, RT>), grid, dim3(kSrWaves * 64), lds, stream, A, lda,
                        reinterpret_cast<const float4*>(Wp), bias, y, ldpart, theta_out, M, N, Kdim, D, par, CG, rc);
   }
   NF_HIP(hipGetLastError());
   return NF_OK;
+}
+
+// 32-row blocks whatever M: 64-row blocks (RT = 4: W read once per 64 rows, one round of workgroups at 129..256 rows,
+// 250 registers) took 577-593 us per 8-layer call at 192 / 256 rows against 478-481 us for two rounds of 32-row blocks.
+template <int K>
+static int launch_k(const float* A, int lda, const float* Wp, const float* bias, float* y, float* ldpart, float* theta_out,
+                    int M, int N, int Kdim, int D, int par, int inverse_op, const RqsConst& rc, hipStream_t stream) {
+  return launch_krt<K, 2>(A, lda, Wp, bias, y, ldpart, theta_out, M, N, Kdim, D, par, inverse_op, rc, stream);
 }
 
 // Wp: launch_small_m_rqs_pack()'s copy of the layer's W; ldpart: [small_m_rqs_groups()][M] floats of this layer;
