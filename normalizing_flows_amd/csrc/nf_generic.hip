@@ -1657,6 +1657,7 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
         // 8-layer call at the MNIST shape and 192 / 256 rows, where this kernel's 158 workgroups took 50 + 5 us per layer)
         const bool small_m_rqs_first =
             j == nlin - 1 && d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3) && n <= 256 && L.K >= 8 * 32 &&
+            !switches().no_splitk &&   // (NF_NO_SPLITK: the kernels of large batches on any batch)
             small_m_rqs_groups(a, lda, (int)n, L.N, L.K, par == 0 ? D / 2 : (D + 1) / 2, rc.K) > 0;
         const bool k5_small = small_m_rqs_first ||
                               ((long long)(k5_npad / 128) * ((n + 127) / 128) <= 128 && L.K >= 8 * 32 &&
