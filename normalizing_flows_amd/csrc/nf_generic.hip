@@ -1613,8 +1613,20 @@ int Plan::walk(float* y, float* ld, const ChainIO& io, hipStream_t stream) {
   if (w1c && w1c_stale && !record_tape) NF_TRY(refresh_w1c(stream));
   const int act = d.activation == NF_ACT_RELU ? 1 : 2;
   const RqsConst rc = make_rqs_const(d);
-  for (long long r0 = 0; r0 < io.rows; r0 += scratch_rows) {
-    const long long n = std::min(scratch_rows, io.rows - r0);
+  // 257..512 rows of a wide masked spline flow: in two blocks through the small-batch kernels (0.76 / 0.95 ms at the
+  // MNIST shape and 384 / 512 rows against 0.89 / 1.10 ms through the split-K route; three blocks -- 640 rows,
+  // 1.23 ms -- lose to the large-batch kernels)
+  long long step_rows = scratch_rows;
+  if (d.kind == NF_KIND_RQS_MASKED && !record_tape && !(x3 && d_wx3) && io.rows > 256 && io.rows <= 512 && nlin > 1 &&
+      !switches().no_splitk) {
+    const Linear& L = linears[(size_t)io.layer_begin * nlin + nlin - 1];
+    const int par = (d.first_mask_parity + io.layer_begin) & 1;
+    if (L.K >= 8 * 32 && (L.K & 3) == 0 &&
+        small_m_rqs_groups(d_scratch, L.K, 256, L.N, L.K, par == 0 ? D / 2 : (D + 1) / 2, rc.K) > 0)
+      step_rows = std::min<long long>(scratch_rows, 256);
+  }
+  for (long long r0 = 0; r0 < io.rows; r0 += step_rows) {
+    const long long n = std::min(step_rows, io.rows - r0);
     float* yc = y + r0 * D;
     float* ldc = ld + r0;
     float* buf[3] = {d_scratch, d_scratch + (size_t)scratch_rows * act_width,

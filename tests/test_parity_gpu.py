@@ -918,6 +918,19 @@ def test_small_batch_last_linear_and_spline_in_one_launch(nfa, monkeypatch, D, h
     assert not np.array_equal(other, got) or rows * D < 4096   # the switch does select another summation order
 
 
+def test_two_blocks_of_small_batch_rows(nfa, monkeypatch):
+    """257..512 rows of a wide masked spline flow are walked as two blocks of <= 256 rows through the small-batch kernels:
+    every row's bits equal those of the same row evaluated in a batch of its own block size (a block's kernels do not see
+    the other block), and the whole agrees with the oracle."""
+    spec = O.make_rqs_spec(2, event_size=400, hidden=(64, 256), num_bins=8, range_min=-3.0, range_max=3.0, final_std=0.05)
+    x = (np.random.default_rng(17).standard_normal((300, 400)) * 1.2).astype(np.float32)
+    f = rqs_flow(nfa, spec)
+    whole = f.log_prob(x)
+    assert np.array_equal(whole[:256], f.log_prob(x[:256]))
+    assert np.array_equal(whole[256:], f.log_prob(x[256:]))
+    assert_spline_forward(f, spec, x, "two blocks of small-batch rows")
+
+
 def test_small_batch_weight_copy_follows_the_weights(nfa):
     """The operand-ordered copy of the last Linears (made by the first small-batch walk) is re-laid after an optimiser
     step and after set_weights: log_prob of 64 rows equals that of a fresh handle on the same weights."""
